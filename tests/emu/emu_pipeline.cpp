@@ -1,0 +1,174 @@
+/*
+ * emu_pipeline.cpp -- TEST INFRASTRUCTURE ONLY.
+ *
+ * Compiles the kernel sources of zsc_amd/csrc with -DZSC_WAVE_EMU (wave.h), i.e.
+ * runs the very same wavefront code lane by lane on the host, so the CPU test
+ * suite (-m "not gpu") can check kernel logic against the oracle without a GPU.
+ * Nothing here is shipped or reachable from libzsc_hip.so.
+ */
+#define ZSC_WAVE_EMU 1
+#include <stdint.h>
+#include <stdlib.h>
+#include <string.h>
+#include <vector>
+
+struct uint4 { uint32_t x, y, z, w; };
+
+#include "../../zsc_amd/csrc/hash_sort.h"
+#include "../../zsc_amd/csrc/lz_parse.h"
+#include "../../zsc_amd/csrc/huff_plan.h"
+#include "../../zsc_amd/csrc/bit_emit.h"
+#include "../../zsc_amd/csrc/checksum.h"
+
+static const ZdLevel kLevels[10] = {
+    {0, 0, 0, 0, 0},       {4, 4, 8, 4, 0},       {4, 5, 16, 8, 0},     {4, 6, 32, 32, 0},
+    {4, 4, 16, 16, 1},     {8, 16, 32, 32, 1},    {8, 16, 128, 128, 1}, {8, 32, 128, 256, 1},
+    {32, 128, 258, 1024, 1}, {32, 258, 258, 4096, 1}};
+
+struct EmuChains {
+    std::vector<uint8_t> in;
+    uint32_t n, ntiles;
+    std::vector<uint32_t> sorted, tmp;
+    std::vector<uint16_t> rank, dir;
+};
+
+static void build_chains(EmuChains &c, const uint8_t *src, uint32_t n)
+{
+    c.n = n;
+    c.in.assign((size_t)n + 64, 0);
+    memcpy(c.in.data(), src, n);
+    c.ntiles = n == 0 ? 1 : (n + ZD_TILE - 1) / ZD_TILE;
+    c.sorted.assign((size_t)c.ntiles * ZD_TILE, 0xdeadbeef);
+    c.tmp.assign((size_t)c.ntiles * ZD_TILE, 0xdeadbeef);
+    c.rank.assign((size_t)n + 64, 0xdead);
+    c.dir.assign((size_t)c.ntiles * ZD_DIR_STRIDE, 0xdead);
+    uint32_t owners = n >= 3 ? n - 2 : 0; /* positions 0..n-3 own a 3-byte string */
+    for (uint32_t t = 0; t < c.ntiles; t++) {
+        HsTile tile;
+        tile.in = c.in.data();
+        tile.n = n;
+        tile.start = t * ZD_TILE;
+        tile.m = owners > tile.start ? (owners - tile.start < ZD_TILE ? owners - tile.start : ZD_TILE) : 0;
+        tile.sorted = c.sorted.data() + (size_t)t * ZD_TILE;
+        tile.tmp = c.tmp.data() + (size_t)t * ZD_TILE;
+        tile.rank = c.rank.data();
+        tile.dir = (t + 1 < c.ntiles) ? c.dir.data() + (size_t)t * ZD_DIR_STRIDE : nullptr;
+        HsLds lds;
+        for (int ph = 0; ph < HS_PHASES; ph++)
+            for (int w = 0; w < HS_WAVES; w++)
+                hash_sort_phase(tile, &lds, w, ph);
+    }
+}
+
+extern "C" int emu_sort(const uint8_t *src, uint32_t n, uint32_t *sorted_out, uint16_t *rank_out,
+                        uint16_t *dir_out)
+{
+    EmuChains c;
+    build_chains(c, src, n);
+    memcpy(sorted_out, c.sorted.data(), c.sorted.size() * 4);
+    memcpy(rank_out, c.rank.data(), (size_t)n * 2);
+    memcpy(dir_out, c.dir.data(), c.dir.size() * 2);
+    return (int)c.ntiles;
+}
+
+extern "C" int emu_parse(const uint8_t *src, uint32_t n, int level, int strategy, uint32_t *syms,
+                         uint32_t *nsyms, ZdBlockRec *blocks, uint32_t *nblocks)
+{
+    if (level < 4 || level > 9)
+        return -2;
+    EmuChains c;
+    build_chains(c, src, n);
+    LzJob job;
+    ZdParseOut out = {0, 0};
+    job.in = c.in.data();
+    job.n = n;
+    job.sorted = c.sorted.data();
+    job.rank = c.rank.data();
+    job.dir = c.dir.data();
+    job.syms = syms;
+    job.blocks = blocks;
+    job.out = &out;
+    job.cfg = kLevels[level];
+    job.strategy = (uint32_t)strategy;
+    LzLds *lds = (LzLds *)malloc(sizeof(LzLds));
+    memset(lds, 0xA5, sizeof(LzLds));
+    lz_parse_lazy(job, lds);
+    free(lds);
+    *nsyms = out.nsyms;
+    *nblocks = out.nblocks;
+    return 0;
+}
+
+extern "C" uint32_t emu_adler32(const uint8_t *src, uint32_t n)
+{
+    std::vector<uint8_t> in((size_t)n + 64, 0);
+    memcpy(in.data(), src, n);
+    return ck_adler32(in.data(), n);
+}
+
+extern "C" uint32_t emu_crc32(const uint8_t *src, uint32_t n)
+{
+    std::vector<uint8_t> in((size_t)n + 64, 0);
+    memcpy(in.data(), src, n);
+    CkLds lds;
+    return ck_crc32(in.data(), n, &lds);
+}
+
+/* the whole deflate pipeline, kernel by kernel, for one buffer */
+extern "C" int emu_compress(const uint8_t *src, uint32_t n, int level, int wrap, int strategy,
+                            uint8_t *out, uint32_t out_cap, uint32_t *out_len)
+{
+    if (level < 4 || level > 9)
+        return -2;
+    EmuChains c;
+    build_chains(c, src, n);
+    std::vector<uint32_t> syms((size_t)n + 64);
+    uint32_t max_blocks = n / ZD_SYM_CAP + 2;
+    std::vector<ZdBlockRec> recs(max_blocks);
+    std::vector<ZdBlockPlan> plans(max_blocks);
+    ZdParseOut po = {0, 0};
+    LzJob job;
+    job.in = c.in.data();
+    job.n = n;
+    job.sorted = c.sorted.data();
+    job.rank = c.rank.data();
+    job.dir = c.dir.data();
+    job.syms = syms.data();
+    job.blocks = recs.data();
+    job.out = &po;
+    job.cfg = kLevels[level];
+    job.strategy = (uint32_t)strategy;
+    LzLds *lds = (LzLds *)malloc(sizeof(LzLds));
+    memset(lds, 0xA5, sizeof(LzLds));
+    lz_parse_lazy(job, lds);
+    free(lds);
+
+    ZdBuf buf;
+    memset(&buf, 0, sizeof buf);
+    buf.in_len = n;
+    buf.out_cap = out_cap;
+    buf.level = (uint32_t)level;
+    buf.wrap = (uint32_t)wrap;
+    buf.strategy = (uint32_t)strategy;
+    ZdResult res;
+    memset(&res, 0, sizeof res);
+    CkLds ck;
+    res.adler = wrap == 1 ? ck_adler32(c.in.data(), n) : wrap == 2 ? ck_crc32(c.in.data(), n, &ck) : 0;
+
+    for (uint32_t b = 0; b < po.nblocks; b++) {
+        HpLds hl;
+        memset(&hl, 0x5A, sizeof hl);
+        huff_plan_block(syms.data() + recs[b].sym_begin, &recs[b], (uint32_t)strategy, &plans[b], &hl);
+    }
+    std::vector<uint32_t> outw(((size_t)out_cap + 64) / 4 + 4, 0xCDCDCDCD);
+    layout_buffer(&buf, &po, recs.data(), plans.data(), &res, (uint8_t *)outw.data());
+    for (uint32_t b = 0; b < po.nblocks; b++) {
+        BeLds bl;
+        memset(&bl, 0x77, sizeof bl);
+        emit_block(c.in.data(), syms.data() + recs[b].sym_begin, &recs[b], &plans[b], outw.data(), &bl);
+    }
+    *out_len = res.out_len;
+    if (res.status == 0)
+        memcpy(out, outw.data(), res.out_len);
+    return res.status;
+}

@@ -1,0 +1,249 @@
+/*
+ * hash_sort.h -- kernel 1: per-tile hash-chain construction by sorting.
+ *
+ * Replaces the reference's INSERT_STRING / head[] / prev[] machinery
+ * (src/deflate.c:174-189, slide_hash :204-231).  For compression levels 4-9
+ * every position is inserted into the chain of its 3-byte hash
+ * (src/deflate.c:2018,2069-2075), so "the chain of p" is simply: all earlier
+ * positions with the same hash, newest first.  Sorting a tile's positions by
+ * (hash, position) makes that chain a CONTIGUOUS, descending run that a
+ * wavefront can fetch 64 candidates at a time with one coalesced load, instead
+ * of chasing prev[] links one dependent load at a time.
+ *
+ * One workgroup of HS_WAVES wavefronts per tile of 32 768 positions.  Stable
+ * LSD radix sort in two passes over the 15-bit hash (8 low bits, 7 high bits):
+ *   phase 0  clear counters
+ *   phase 1  per-wave-slice histogram of the low digit
+ *   phase 2  exclusive scan (digit-major, wave-minor)
+ *   phase 3  stable scatter into tmp: rank inside a 64-element step comes from
+ *            ballot "multi-split" (one ballot per digit bit), not from atomics
+ *   phase 4  per-wave-slice histogram of the high digit over tmp
+ *   phase 5  scan
+ *   phase 6  stable scatter into sorted[] + rank[]
+ *   phase 7  bucket directory dir[h] = first sorted index with hash >= h
+ * Counters are tiny (6 KiB of LDS), so many tiles are resident per CU.
+ *
+ * Bytes per input byte (TILE positions): read 2 (input, twice) + tmp 4w+4r +
+ * sorted 4w(+4r for dir) + rank 2w + dir 2w.
+ */
+#ifndef ZSC_HASH_SORT_H
+#define ZSC_HASH_SORT_H
+
+#include "wave.h"
+#include "zsc_dev.h"
+
+#define HS_WAVES 4
+
+typedef struct {
+    uint32_t cnt0[256 * HS_WAVES];
+    uint32_t cnt1[128 * HS_WAVES];
+} HsLds;
+
+typedef struct {
+    const uint8_t *in;  /* the tile's buffer */
+    uint32_t n;         /* buffer length */
+    uint32_t start;     /* absolute position of the tile's first byte */
+    uint32_t m;         /* positions of this tile that own a 3-byte string (pos <= n-3) */
+    uint32_t *sorted;   /* TILE entries */
+    uint32_t *tmp;      /* TILE entries */
+    uint16_t *rank;     /* per position of the buffer */
+    uint16_t *dir;      /* DIR_STRIDE entries, or null when no later tile will look back */
+} HsTile;
+
+/* UPDATE_HASH over three bytes, reference src/deflate.c:174-175 */
+DEV uint32_t hs_hash3(const uint8_t *in, uint32_t pos, uint32_t n)
+{
+    uint32_t b0, b1, b2;
+    if (pos + 4 <= n) {
+        uint32_t w = ld_u32(in + pos);
+        b0 = w & 0xff;
+        b1 = (w >> 8) & 0xff;
+        b2 = (w >> 16) & 0xff;
+    } else {
+        b0 = in[pos];
+        b1 = in[pos + 1];
+        b2 = in[pos + 2];
+    }
+    return ((b0 << 10) ^ (b1 << 5) ^ b2) & ZD_HASH_MASK;
+}
+
+DEV uint32_t hs_slice(uint32_t m)
+{
+    uint32_t per = (m + HS_WAVES * WAVE - 1) / (HS_WAVES * WAVE);
+    return per * WAVE;
+}
+
+/* stable scatter of one pass; key_of_tmp selects pass 2 (source = tmp) */
+DEV void hs_scatter(const HsTile &t, HsLds *lds, int w, int pass)
+{
+    const uint32_t slice = hs_slice(t.m);
+    const uint32_t lo = (uint32_t)w * slice;
+    const int nbits = pass == 0 ? 8 : 7;
+    uint32_t *off = pass == 0 ? lds->cnt0 : lds->cnt1;
+
+    for (uint32_t s = lo; s < lo + slice && s < t.m; s += WAVE) {
+        LANEVAR(uint32_t, ent);
+        LANEVAR(uint32_t, dig);
+        LANEVAR(int, ok);
+        FOR_LANES
+        {
+            uint32_t i = s + (uint32_t)LANE;
+            LV(ok) = i < t.m;
+            uint32_t e = 0;
+            if (LV(ok)) {
+                if (pass == 0) {
+                    uint32_t h = hs_hash3(t.in, t.start + i, t.n);
+                    e = i | (h << 16);
+                } else {
+                    e = t.tmp[i];
+                }
+            }
+            LV(ent) = e;
+            LV(dig) = pass == 0 ? ((e >> 16) & 0xff) : (e >> 24);
+        }
+        /* ballot multi-split: lanes with the same digit find each other */
+        LANEVAR(uint64_t, peers);
+        uint64_t live = BALLOT(ok);
+        FOR_LANES { LV(peers) = live; }
+        for (int b = 0; b < nbits; b++) {
+            LANEVAR(int, bit);
+            FOR_LANES { LV(bit) = (int)((LV(dig) >> b) & 1u); }
+            uint64_t ones = BALLOT(bit);
+            FOR_LANES { LV(peers) &= LV(bit) ? ones : ~ones; }
+        }
+        LANEVAR(uint32_t, dst);
+        FOR_LANES
+        {
+            if (LV(ok)) {
+                uint32_t before = (uint32_t)POPC64(LV(peers) & ((1ull << LANE) - 1ull));
+                LV(dst) = off[LV(dig) * HS_WAVES + (uint32_t)w] + before;
+            }
+        }
+        FOR_LANES
+        {
+            if (LV(ok)) {
+                uint64_t mine = LV(peers);
+                if ((mine & ((1ull << LANE) - 1ull)) == 0) /* first lane of its digit group */
+                    off[LV(dig) * HS_WAVES + (uint32_t)w] += (uint32_t)POPC64(mine);
+            }
+        }
+        FOR_LANES
+        {
+            if (LV(ok)) {
+                if (pass == 0) {
+                    t.tmp[LV(dst)] = LV(ent);
+                } else {
+                    t.sorted[LV(dst)] = LV(ent);
+                    t.rank[t.start + (LV(ent) & ZD_TILE_MASK)] = (uint16_t)LV(dst);
+                }
+            }
+        }
+    }
+}
+
+DEV void hs_count(const HsTile &t, HsLds *lds, int w, int pass)
+{
+    const uint32_t slice = hs_slice(t.m);
+    const uint32_t lo = (uint32_t)w * slice;
+    uint32_t *cnt = pass == 0 ? lds->cnt0 : lds->cnt1;
+    for (uint32_t s = lo; s < lo + slice && s < t.m; s += WAVE) {
+        FOR_LANES
+        {
+            uint32_t i = s + (uint32_t)LANE;
+            if (i < t.m) {
+                uint32_t d;
+                if (pass == 0)
+                    d = hs_hash3(t.in, t.start + i, t.n) & 0xff;
+                else
+                    d = t.tmp[i] >> 24;
+                LDS_ADD_U32(&cnt[d * HS_WAVES + (uint32_t)w], 1u);
+            }
+        }
+    }
+}
+
+/* exclusive scan of ndig*HS_WAVES counters, digit-major; done by wave 0 */
+DEV void hs_scan(uint32_t *cnt, int ndig)
+{
+    uint32_t run = 0;
+    const int total = ndig * HS_WAVES;
+    for (int s = 0; s < total; s += WAVE) {
+        LANEVAR(uint32_t, v);
+        LANEVAR(uint32_t, ex);
+        FOR_LANES { LV(v) = cnt[s + LANE]; }
+        uint32_t tot;
+        WAVE_EXSCAN(v, ex, tot);
+        FOR_LANES { cnt[s + LANE] = run + LV(ex); }
+        run += tot;
+    }
+}
+
+DEV void hs_directory(const HsTile &t, int w)
+{
+    /* bucket starts: sorted index i opens every bucket in (h[i-1], h[i]] */
+    for (uint32_t s = (uint32_t)w * WAVE; s < t.m; s += HS_WAVES * WAVE) {
+        FOR_LANES
+        {
+            uint32_t i = s + (uint32_t)LANE;
+            if (i < t.m) {
+                uint32_t h = t.sorted[i] >> 16;
+                int32_t hp = i == 0 ? -1 : (int32_t)(t.sorted[i - 1] >> 16);
+                for (int32_t hh = hp + 1; hh <= (int32_t)h; hh++)
+                    t.dir[hh] = (uint16_t)i;
+            }
+        }
+    }
+    /* buckets past the last occupied one (and the end sentinel) point at m */
+    int32_t hl = t.m == 0 ? -1 : (int32_t)(t.sorted[t.m - 1] >> 16);
+    for (int32_t s = hl + 1 + w * WAVE; s <= 32768; s += HS_WAVES * WAVE) {
+        FOR_LANES
+        {
+            int32_t hh = s + LANE;
+            if (hh <= 32768)
+                t.dir[hh] = (uint16_t)t.m;
+        }
+    }
+}
+
+/* one phase of the tile sort, executed by wave `w` of the tile's workgroup;
+ * the caller puts a workgroup barrier between phases */
+DEV void hash_sort_phase(const HsTile &t, HsLds *lds, int w, int phase)
+{
+    switch (phase) {
+    case 0:
+        for (int i = w * WAVE; i < 256 * HS_WAVES; i += HS_WAVES * WAVE) {
+            FOR_LANES { lds->cnt0[i + LANE] = 0; }
+        }
+        for (int i = w * WAVE; i < 128 * HS_WAVES; i += HS_WAVES * WAVE) {
+            FOR_LANES { lds->cnt1[i + LANE] = 0; }
+        }
+        break;
+    case 1:
+        hs_count(t, lds, w, 0);
+        break;
+    case 2:
+        if (w == 0)
+            hs_scan(lds->cnt0, 256);
+        break;
+    case 3:
+        hs_scatter(t, lds, w, 0);
+        break;
+    case 4:
+        hs_count(t, lds, w, 1);
+        break;
+    case 5:
+        if (w == 0)
+            hs_scan(lds->cnt1, 128);
+        break;
+    case 6:
+        hs_scatter(t, lds, w, 1);
+        break;
+    case 7:
+        if (t.dir)
+            hs_directory(t, w);
+        break;
+    }
+}
+#define HS_PHASES 8
+
+#endif

@@ -1,0 +1,165 @@
+/*
+ * wave.h -- the two spellings of "one 64-lane wavefront" used by the kernels.
+ *
+ * Every kernel body in this directory is written once, as code for ONE gfx950
+ * wavefront (64 lanes), in a style where
+ *   - wave-uniform state (parse position, best length, chain budget ...) is an
+ *     ordinary scalar,
+ *   - per-lane state is declared with LANEVAR() and touched only inside a
+ *     FOR_LANES { } region through LV(),
+ *   - lanes talk to each other only through the collectives below, called from
+ *     wave-uniform control flow.
+ *
+ * Built by hipcc (the product) FOR_LANES expands to nothing: the region is
+ * ordinary SIMT code, LV(x) is the lane's register, the collectives are
+ * v_cmp+s_mov ballots, v_readlane and DPP/LDS shuffles.
+ *
+ * Built with -DZSC_WAVE_EMU by g++ (tests/emu only, never shipped and never
+ * linked into libzsc_hip.so) FOR_LANES is a loop over 64 lanes and LV(x) indexes
+ * a 64-entry array, which lets the CPU test-suite execute the very same kernel
+ * source lane by lane and compare every intermediate with the oracle.  This is
+ * a test harness for kernel logic, not a fallback: the library has no code
+ * path that reaches it.
+ */
+#ifndef ZSC_WAVE_H
+#define ZSC_WAVE_H
+
+#include <stdint.h>
+
+#define WAVE 64
+
+#ifdef ZSC_WAVE_EMU
+/* ------------------------------------------------------------------ host */
+#include <string.h>
+
+#define DEV static inline
+#define GLOBAL_FN static
+#define LDS_DECL(T, name, n) T name[n]
+#define LANEVAR(T, name) T name[WAVE]
+#define LV(name) name[_lane]
+#define FOR_LANES for (int _lane = 0; _lane < WAVE; ++_lane)
+#define LANE (_lane)
+#define ON_LANE0
+#define WG_BARRIER() ((void)0)
+
+template <typename T>
+static inline uint64_t emu_ballot(const T *p)
+{
+    uint64_t m = 0;
+    for (int i = 0; i < WAVE; i++)
+        if (p[i])
+            m |= 1ull << i;
+    return m;
+}
+#define BALLOT(name) emu_ballot(name)
+#define READLANE(name, l) (name[(l)])
+
+/* exclusive prefix sum over lanes; total returned */
+template <typename T>
+static inline T emu_exscan(const T *in, T *out)
+{
+    T run = 0;
+    for (int i = 0; i < WAVE; i++) {
+        T v = in[i];
+        out[i] = run;
+        run += v;
+    }
+    return run;
+}
+#define WAVE_EXSCAN(in, out, total) ((total) = emu_exscan(in, out))
+
+template <typename T>
+static inline T emu_sum(const T *in)
+{
+    T run = 0;
+    for (int i = 0; i < WAVE; i++)
+        run += in[i];
+    return run;
+}
+#define WAVE_SUM(in) emu_sum(in)
+
+static inline uint32_t ld_u32(const uint8_t *p)
+{
+    uint32_t v;
+    memcpy(&v, p, 4);
+    return v;
+}
+static inline uint32_t ld_u16(const uint8_t *p)
+{
+    uint16_t v;
+    memcpy(&v, p, 2);
+    return v;
+}
+#define LDS_ADD_U32(ptr, v) (*(ptr) += (v))
+#define LDS_OR_U32(ptr, v) (*(ptr) |= (v))
+#define GLOBAL_OR_U32(ptr, v) (*(ptr) |= (v))
+#define CTZ64(x) __builtin_ctzll(x)
+#define CTZ32(x) __builtin_ctz(x)
+#define POPC64(x) __builtin_popcountll(x)
+#define COPY16(dst, src) memcpy((dst), (src), 16)
+
+#else
+/* ---------------------------------------------------------------- gfx950 */
+#include <hip/hip_runtime.h>
+
+#define DEV __device__ __forceinline__
+#define GLOBAL_FN __global__
+#define LDS_DECL(T, name, n) __shared__ T name[n]
+#define LANEVAR(T, name) T name
+#define LV(name) name
+#define FOR_LANES
+#define LANE ((int)(threadIdx.x & 63))
+#define ON_LANE0 if ((threadIdx.x & 63) == 0)
+#define WG_BARRIER() __syncthreads()
+
+#define BALLOT(name) __ballot(name)
+/* lane index must be wave-uniform: force it into an SGPR so this is v_readlane_b32 */
+#define READLANE(name, l) \
+    ((decltype(name))__builtin_amdgcn_readlane((int)(name), __builtin_amdgcn_readfirstlane((int)(l))))
+
+DEV uint32_t wave_exscan_u32(uint32_t v, uint32_t &total)
+{
+    uint32_t x = v;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+        uint32_t y = __shfl_up(x, d);
+        if ((int)(threadIdx.x & 63) >= d)
+            x += y;
+    }
+    total = __shfl(x, 63);
+    return x - v;
+}
+#define WAVE_EXSCAN(in, out, total) ((out) = wave_exscan_u32((in), (total)))
+
+DEV uint64_t wave_sum_u64(uint64_t v)
+{
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1)
+        v += __shfl_xor(v, d);
+    return v;
+}
+#define WAVE_SUM(in) wave_sum_u64(in)
+
+DEV uint32_t ld_u32(const uint8_t *p)
+{
+    uint32_t v;
+    __builtin_memcpy(&v, p, 4);
+    return v;
+}
+DEV uint32_t ld_u16(const uint8_t *p)
+{
+    uint16_t v;
+    __builtin_memcpy(&v, p, 2);
+    return v;
+}
+#define LDS_ADD_U32(ptr, v) atomicAdd((ptr), (v))
+#define LDS_OR_U32(ptr, v) atomicOr((ptr), (v))
+#define GLOBAL_OR_U32(ptr, v) atomicOr((ptr), (v))
+#define CTZ64(x) __builtin_ctzll(x)
+#define CTZ32(x) __builtin_ctz(x)
+#define POPC64(x) __builtin_popcountll(x)
+/* both sides 16-byte aligned: one global_load_dwordx4 + one ds_write_b128 */
+#define COPY16(dst, src) (*(uint4 *)(dst) = *(const uint4 *)(src))
+#endif
+
+#endif /* ZSC_WAVE_H */

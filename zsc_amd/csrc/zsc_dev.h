@@ -1,0 +1,105 @@
+/*
+ * zsc_dev.h -- data layout shared by the host runtime and the gfx950 kernels.
+ *
+ * Vocabulary follows the reference (window, hash chain, block, lit/len + dist
+ * symbols); see DESIGN.md "data layout in HBM".
+ *
+ *   input    all buffers of a batch back to back, each starting 16-byte aligned
+ *   tiles    every buffer is cut into tiles of TILE = 32 768 positions (= the
+ *            reference's w_size, src/deflate.c:344); one hash-sort workgroup per
+ *            tile, tiles of all buffers numbered consecutively
+ *   sorted   per tile, its positions ordered by (hash, position):
+ *            entry = pos_in_tile | hash << 16           (u32, TILE per tile)
+ *   rank     per input position, its index inside its tile's sorted array (u16)
+ *   dir      per tile, first sorted index of every hash bucket (u16, DIR_STRIDE)
+ *   symbols  per buffer, the LZ77 symbol stream: dist << 16 | lc   (u32)
+ *   blocks   per buffer, the block cuts the parser made (BlockRec)
+ *   plans    per block, Huffman code tables + header bits (BlockPlan)
+ */
+#ifndef ZSC_DEV_H
+#define ZSC_DEV_H
+
+#include <stdint.h>
+
+#define ZD_TILE 32768u         /* w_size for window_bits 15 */
+#define ZD_TILE_MASK 32767u
+#define ZD_MAX_DIST 32506u     /* w_size - MIN_LOOKAHEAD, include/zsc/deflate.h:308 */
+#define ZD_MIN_LOOKAHEAD 262u
+#define ZD_TOO_FAR 4096u
+#define ZD_HASH_BITS 15u       /* mem_level 8, src/deflate.c:347 */
+#define ZD_HASH_MASK 0x7fffu
+#define ZD_HASH_SHIFT 5u
+#define ZD_SYM_CAP 16383u      /* lit_bufsize - 1, include/zsc/deflate.h:343 */
+#define ZD_DIR_STRIDE 32776u   /* 32769 entries, padded to a multiple of 8 */
+#define ZD_ENTRY_NONE 0xffffffffu
+
+#define ZD_RING 36864u         /* LDS window ring of the parser: 32 KiB history + one 4 KiB chunk */
+#define ZD_CHUNK 4096u
+
+#define ZD_HDR_BYTES 320u      /* room for one dynamic block header (HLIT..code lengths) */
+
+/* per-level search parameters, reference src/deflate.c:146-158 */
+typedef struct {
+    uint16_t good, lazy, nice, chain;
+    uint32_t slow; /* 1: lazy parse (levels 4-9), 0: greedy (1-3) */
+} ZdLevel;
+
+/* one buffer of a batch */
+typedef struct {
+    uint64_t in_off;    /* byte offset of the buffer in the batch input */
+    uint64_t out_off;   /* byte offset of its stream in the batch output (4-byte aligned) */
+    uint64_t sym_off;   /* first symbol slot */
+    uint32_t in_len;
+    uint32_t out_cap;
+    uint32_t tile0;     /* index of its first tile */
+    uint32_t ntiles;
+    uint32_t blk0;      /* index of its first BlockRec / BlockPlan */
+    uint32_t max_blocks;
+    uint32_t level;     /* 1..9 */
+    uint32_t wrap;      /* 0 raw, 1 zlib, 2 gzip */
+    uint32_t strategy;  /* 0 default, 1 filtered, 4 fixed */
+    uint32_t pad;
+} ZdBuf;
+
+/* what the parser reports per buffer */
+typedef struct {
+    uint32_t nsyms;
+    uint32_t nblocks;
+} ZdParseOut;
+
+/* one deflate block as cut by the parser (reference FLUSH_BLOCK, src/deflate.c:1660-1674) */
+typedef struct {
+    uint32_t sym_begin; /* relative to the buffer's sym_off */
+    uint32_t sym_count;
+    uint32_t in_begin;
+    uint32_t in_len;
+    uint32_t stored_ok;
+    uint32_t last;
+} ZdBlockRec;
+
+#define ZD_BT_STORED 0u
+#define ZD_BT_STATIC 1u
+#define ZD_BT_DYNAMIC 2u
+
+/* Huffman plan of one block (reference _tr_flush_block, src/trees.c:874-941) */
+typedef struct {
+    uint32_t type;       /* ZD_BT_* */
+    uint32_t body_bits;  /* static/dynamic: 3-bit header + trees + symbols + END_BLOCK */
+    uint32_t hdr_bits;   /* dynamic: bits in hdr[] (HLIT, HDIST, HCLEN, lengths) */
+    uint32_t bit_off;    /* filled by the layout pass: first bit of the block in the stream */
+    uint16_t lcode[286]; /* bit-reversed codes, ready to emit LSB first */
+    uint8_t llen[286];
+    uint16_t dcode[30];
+    uint8_t dlen[30];
+    uint8_t hdr[ZD_HDR_BYTES];
+} ZdBlockPlan;
+
+/* per-buffer result */
+typedef struct {
+    uint32_t out_len; /* bytes of the complete stream */
+    int32_t status;   /* ZlibReturn */
+    uint32_t adler;   /* adler32 or crc32 of the input */
+    uint32_t pad;
+} ZdResult;
+
+#endif
