@@ -1,0 +1,104 @@
+/*
+ * zsc_hip.h -- batched / device-resident entry points of libzsc_hip.so.
+ *
+ * Extension of the reference API (SURVEY.md 8b "extension we add"): one
+ * zsc_compress() call cannot amortise a kernel launch, so the library also
+ * accepts MANY independent buffers per call.  Every item has exactly the
+ * semantics of one reference zsc_compress2()/zsc_uncompress2() call
+ * (src/zsc_compress.c:50-160, src/zsc_uncompr.c:44-154) with
+ * max_block_len >= source_len: the stream produced for an item is byte-identical
+ * to the reference's, and its status is the ZlibReturn the reference returns.
+ *
+ * C ABI only: plain pointers and sizes, no C++/torch types.  The reference-side
+ * binding a maintainer would add is shown in INTEGRATION.md.
+ */
+#ifndef ZSC_HIP_H
+#define ZSC_HIP_H
+
+#include <stdint.h>
+
+#include "zsc/zlib_types_pub.h"
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* library / device -------------------------------------------------------- */
+
+/* 0 when a gfx950 device is usable; otherwise a negative ZlibReturn and a message
+ * through ZSC_WARN.  Called implicitly by every other entry point. */
+I32 zsc_hip_init(I32 device_ordinal);
+
+/* human readable "device name | arch | CUs", valid until the next call */
+const char *zsc_hip_device_info(void);
+
+/* host-pointer batches ---------------------------------------------------- */
+
+/* Compress `count` independent buffers (host memory).  Item i:
+ *   sources[i], source_lens[i]          input
+ *   dests[i], dest_lens[i]              in: capacity of dests[i]; out: bytes written
+ *   statuses[i]                         ZlibReturn of the item (Z_OK, Z_BUF_ERROR ...)
+ * level / window_bits / mem_level / strategy as zsc_compress2 (reference
+ * include/zsc/zsc_pub.h:258).  Returns Z_OK when the batch ran (look at statuses
+ * for the items), or the error that stopped the whole batch. */
+ZlibReturn zsc_hip_compress_batch(U32 count, const U8 *const *sources, const U32 *source_lens,
+                                  U8 *const *dests, U32 *dest_lens, I32 *statuses, I32 level,
+                                  I32 window_bits, I32 mem_level, ZlibStrategy strategy);
+
+/* Decompress `count` independent streams (host memory).  source_lens[i]: in bytes
+ * available, out bytes consumed (reference zsc_uncompress2, zsc_pub.h:385). */
+ZlibReturn zsc_hip_uncompress_batch(U32 count, const U8 *const *sources, U32 *source_lens,
+                                    U8 *const *dests, U32 *dest_lens, I32 *statuses,
+                                    I32 window_bits);
+
+/* device-resident plans --------------------------------------------------- */
+
+/* A plan fixes the shape of a batch (how many buffers, how long each one is, the
+ * codec parameters), owns all scratch memory in HBM and can be run many times on
+ * inputs that already live in device memory.  Layout of the device buffers:
+ *   input   buffer i occupies [in_offsets[i], in_offsets[i] + source_lens[i]);
+ *           offsets are multiples of 16; 64 readable bytes must follow the last buffer
+ *   output  stream i is written at out_offsets[i] (multiple of 16), capacity
+ *           out_caps[i] >= zsc_compress_get_max_output_size(source_lens[i], ...)
+ * zsc_hip_deflate_plan_layout() fills offsets/capacities with the tightest legal
+ * layout and returns the two buffer sizes to allocate. */
+typedef struct zsc_hip_deflate_plan zsc_hip_deflate_plan;
+
+ZlibReturn zsc_hip_deflate_plan_layout(U32 count, const U32 *source_lens, I32 level,
+                                       I32 window_bits, I32 mem_level, uint64_t *in_offsets,
+                                       uint64_t *out_offsets, U32 *out_caps,
+                                       uint64_t *in_bytes, uint64_t *out_bytes);
+
+ZlibReturn zsc_hip_deflate_plan_create(zsc_hip_deflate_plan **plan, U32 count,
+                                       const U32 *source_lens, const uint64_t *in_offsets,
+                                       const uint64_t *out_offsets, const U32 *out_caps,
+                                       I32 level, I32 window_bits, I32 mem_level,
+                                       ZlibStrategy strategy);
+
+/* Enqueue one full pass (checksum, hash sort, parse, Huffman plan, layout, bit
+ * packing) on `hip_stream` (a hipStream_t, or NULL for the default stream).
+ * Asynchronous: results are read with zsc_hip_deflate_plan_results(). */
+ZlibReturn zsc_hip_deflate_plan_run(zsc_hip_deflate_plan *plan, const void *d_input,
+                                    void *d_output, void *hip_stream);
+
+/* Wait for the last run and fetch per-buffer sizes and statuses (either may be NULL). */
+ZlibReturn zsc_hip_deflate_plan_results(zsc_hip_deflate_plan *plan, U32 *dest_lens,
+                                        I32 *statuses);
+
+/* Per-kernel device time in milliseconds, measured with HIP events recorded on the
+ * run's stream and averaged over every run since profiling was switched on:
+ * index 0 checksum, 1 hash sort, 2 parse, 3 huffman plan, 4 layout, 5 bit emit,
+ * 6 whole pass.  Read after zsc_hip_deflate_plan_results(). */
+#define ZSC_HIP_NKERNELS 7
+void zsc_hip_deflate_plan_profile(zsc_hip_deflate_plan *plan, I32 enable);
+ZlibReturn zsc_hip_deflate_plan_times(zsc_hip_deflate_plan *plan, float *ms_out);
+
+/* bytes of HBM scratch the plan holds */
+uint64_t zsc_hip_deflate_plan_scratch_bytes(const zsc_hip_deflate_plan *plan);
+
+void zsc_hip_deflate_plan_destroy(zsc_hip_deflate_plan *plan);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1251,8 +1251,11 @@ int zo_uncompress(uint8_t *dest, uint32_t *dest_len, const uint8_t *source, uint
                 (void)zo_take(&r, 16);
                 ZO_NEED(32);
                 (void)zo_take(&r, 32);
-                rc = 2;
-                goto done;
+                /* the DICT state returns straight out of inflate() without the exit
+                 * bookkeeping (src/inflate.c:961-965), so nothing counts as consumed */
+                *dest_len = 0;
+                *source_len = 0;
+                return 2;
             }
             (void)zo_take(&r, 16);
         }

@@ -1,0 +1,156 @@
+#!/usr/bin/env python3
+"""Generate tests/golden/*.json from the compiled reference (oracle/_ref/libzsc_ref.so).
+
+Run in the build container (needs /root/reference to compile the reference):
+    python tests/golden/make_golden.py
+The fixtures hold inputs as (kind, size, seed) triples of zsc_amd.corpus (plus the
+input's SHA-256, so generator drift is detected) and the reference's outputs as
+length + SHA-256, with a few complete small streams in hex.  Inflate known-answer
+inputs are the hex strings the reference's own test/infcover.c feeds to inflate
+(:367-371, :399-411, :583-613, :643-658); the expected results come from running
+the reference's zsc_uncompress2 on them here.
+"""
+import hashlib
+import json
+import os
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, ROOT)
+from oracle.oracle_py import Reference, build  # noqa: E402
+from zsc_amd import corpus  # noqa: E402
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+
+
+def sha(b: bytes) -> str:
+    return hashlib.sha256(b).hexdigest()
+
+
+KINDS = ["text", "token", "bitmap", "table", "object", "random", "zero", "runs"]
+SIZES = [0, 1, 2, 3, 258, 259, 4096, 16383, 32768, 40000, 65274, 65275, 65535, 65536, 65537,
+         98304, 150000]
+
+# hex inputs of reference test/infcover.c: (hex, window_bits, dest_cap)
+INFCOVER = [
+    ("63 0", -15, 1), ("63 18 5", -8, 259), ("63 18 68 30 d0 0 0", -8, 259), ("3 0", -15, 1),
+    ("1f 8b 0 0", 31, 0), ("1f 8b 8 80", 31, 0), ("77 85", 15, 0), ("8 99", 0, 0), ("78 9c", 8, 0),
+    ("78 9c 63 0 0 0 1 0 1", 15, 1),
+    ("1f 8b 8 1e 0 0 0 0 0 0 1 0 0 0 0 0 0", 47, 1),
+    ("1f 8b 8 2 0 0 0 0 0 0 1d 26 3 0 0 0 0 0 0 0 0 0", 47, 0),
+    ("78 90", 47, 0), ("8 b8 0 0 0 1", 8, 0), ("78 9c 63 0", 15, 1),
+    ("0 0 0 0 0", -15, 300), ("3 0", -15, 300), ("6", -15, 300), ("1 1 0 fe ff 0", -15, 300),
+    ("fc 0 0", -15, 300), ("4 0 fe ff", -15, 300), ("4 0 24 49 0", -15, 300),
+    ("4 0 24 e9 ff ff", -15, 300), ("4 0 24 e9 ff 6d", -15, 300),
+    ("4 80 49 92 24 49 92 24 71 ff ff 93 11 0", -15, 300),
+    ("4 80 49 92 24 49 92 24 f b4 ff ff c3 84", -15, 300),
+    ("4 c0 81 8 0 0 0 0 20 7f eb b 0 0", -15, 300), ("2 7e ff ff", -15, 300),
+    ("c c0 81 0 0 0 0 0 90 ff 6b 4 0", -15, 300),
+    ("1f 8b 8 0 0 0 0 0 0 0 3 0 0 0 0 1", 47, 300),
+    ("1f 8b 8 0 0 0 0 0 0 0 3 0 0 0 0 0 0 0 0 1", 47, 300),
+    ("5 c0 21 d 0 0 0 80 b0 fe 6d 2f 91 6c", -15, 300),
+    ("5 e0 81 91 24 cb b2 2c 49 e2 f 2e 8b 9a 47 56 9f fb fe ec d2 ff 1f", -15, 300),
+    ("ed c0 1 1 0 0 0 40 20 ff 57 1b 42 2c 4f", -15, 600),
+    ("ed cf c1 b1 2c 47 10 c4 30 fa 6f 35 1d 1 82 59 3d fb be 2e 2a fc f c", -15, 600),
+    ("ed c0 81 0 0 0 0 80 a0 fd a9 17 a9 0 0 0 0 0 0 0 0 0 0 0 0 0 0 0 0 0 "
+     "0 0 0 0 0 0 0 0 0 0 0 0 0 0 0 6", -15, 600),
+    ("2 8 20 80 0 3 0", -15, 258), ("63 18 5 40 c 0", -8, 300),
+    ("e5 e0 81 ad 6d cb b2 2c c9 01 1e 59 63 ae 7d ee fb 4d fd b5 35 41 68 ff 7f 0f 0 0 0", -8, 258),
+    ("25 fd 81 b5 6d 59 b6 6a 49 ea af 35 6 34 eb 8c b9 f6 b9 1e ef 67 49 50 fe ff ff 3f 0 0", -8, 258),
+    ("3 7e 0 0 0 0 0", -8, 258), ("1b 7 0 0 0 0 0", -8, 258),
+    ("d c7 1 ae eb 38 c 4 41 a0 87 72 de df fb 1f b8 36 b1 38 5d ff ff 0", -8, 258),
+    ("63 18 5 8c 10 8 0 0 0 0", -8, 259),
+    ("63 60 60 18 c9 0 8 18 18 18 26 c0 28 0 29 0 0 0", -8, 259),
+    ("63 0 3 0 0 0 0 0", -8, 259),
+]
+
+
+def main():
+    build(ref=True)
+    R = Reference()
+    deflate_cases = []
+    streams = []
+    for size in SIZES:
+        for kind in KINDS:
+            seed = size * 3 + 1
+            data = corpus.make_buffer(kind, size, seed)
+            for level in (1, 6, 9) if size <= 70000 else (6,):
+                for wb in (15, -15, 31):
+                    if wb != 15 and (level != 6 or kind not in ("text", "random")):
+                        continue
+                    rc, out = R.compress(data, level, window_bits=wb)
+                    case = {"kind": kind, "size": size, "seed": seed, "level": level,
+                            "window_bits": wb, "in_sha256": sha(data), "rc": rc,
+                            "out_len": len(out), "out_sha256": sha(out)}
+                    deflate_cases.append(case)
+                    if size in (0, 1, 3, 258, 259) and kind in ("text", "zero") and wb == 15:
+                        streams.append({**case, "in_hex": data.hex(), "out_hex": out.hex()})
+    # the Canterbury-like set (bench workload), level 6 and 9 sizes for seed 0
+    for i, (name, size, kind) in enumerate(corpus.CANTERBURY_LIKE):
+        data = corpus.make_buffer(kind, size, i)
+        for level in (1, 6, 9):
+            rc, out = R.compress(data, level)
+            deflate_cases.append({"kind": kind, "size": size, "seed": i, "level": level,
+                                  "window_bits": 15, "in_sha256": sha(data), "rc": rc,
+                                  "out_len": len(out), "out_sha256": sha(out), "name": name})
+    # other strategies / error codes through the same entry point
+    data = corpus.make_buffer("text", 30000, 5)
+    params = []
+    for wb, ml, st, lvl in [(15, 8, 1, 6), (15, 8, 4, 6), (15, 8, 1, 9), (12, 8, 0, 6), (15, 9, 0, 6),
+                            (15, 1, 0, 6), (-9, 4, 0, 6), (25, 8, 0, 6), (8, 8, 0, 6), (-8, 8, 0, 6),
+                            (15, 0, 0, 6), (15, 10, 0, 6), (7, 8, 0, 6), (15, 8, 5, 6), (15, 8, 0, 10),
+                            (15, 8, 0, -1)]:
+        rc, out = R.compress(data, lvl, window_bits=wb, mem_level=ml, strategy=st)
+        params.append({"window_bits": wb, "mem_level": ml, "strategy": st, "level": lvl, "rc": rc,
+                       "out_len": len(out), "out_sha256": sha(out)})
+    small = []
+    for cap in (0, 1, 2, 100, 12000, 40000):
+        rc, out = R.compress(data, 6, dest_cap=cap)
+        small.append({"dest_cap": cap, "rc": rc, "out_len": len(out), "out_sha256": sha(out)})
+    for wl in (0, 333599, 333600):
+        rc, out = R.compress(data, 6, work_len=wl)
+        small.append({"work_len": wl, "rc": rc, "out_len": len(out)})
+    # multi-section behaviour (SURVEY finding 2): max_block_len < source_len
+    sections = []
+    big = corpus.make_buffer("text", 300000, 9)
+    for mbl in (20000, 100000, 299999):
+        rc, out = R.compress(big, 6, max_block_len=mbl)
+        sections.append({"kind": "text", "size": 300000, "seed": 9, "max_block_len": mbl, "rc": rc,
+                         "out_len": len(out), "out_sha256": sha(out),
+                         "markers": out.count(b"\x00\x00\xff\xff")})
+    # checksums
+    sums = []
+    for n in (0, 1, 15, 16, 17, 5551, 5552, 5553, 11105, 65536, 150001):
+        d = corpus.make_buffer("random", n, n + 2)
+        sums.append({"size": n, "seed": n + 2, "adler32": R.adler32(d), "crc32": R.crc32(d)})
+    # inflate known answers
+    kats = []
+    for hx, wb, cap in INFCOVER:
+        raw = bytes(int(x, 16) for x in hx.split())
+        rc, out, used = R.uncompress(raw, cap, wb)
+        kats.append({"hex": hx, "window_bits": wb, "dest_cap": cap, "rc": rc, "out_hex": out.hex(),
+                     "consumed": used})
+    # corrupted / truncated streams of a real buffer
+    corrupt = []
+    src = corpus.make_buffer("text", 20000, 3)
+    rc, good = R.compress(src, 6)
+    for pos in (0, 1, 2, 10, len(good) // 2, len(good) - 5, len(good) - 1):
+        bad = bytearray(good)
+        bad[pos] = (bad[pos] + 1) & 0xff
+        rc, out, used = R.uncompress(bytes(bad), len(src), 15)
+        corrupt.append({"flip": pos, "rc": rc, "out_len": len(out), "consumed": used,
+                        "prefix_ok": src.startswith(out[:64])})
+    for cut in (1, 2, 7, len(good) // 2, len(good) - 4, len(good) - 1):
+        rc, out, used = R.uncompress(good[:cut], len(src), 15)
+        corrupt.append({"cut": cut, "rc": rc, "out_len": len(out), "consumed": used,
+                        "out_sha256": sha(out)})
+    json.dump({"deflate": deflate_cases, "streams": streams, "params": params, "small": small,
+               "sections": sections}, open(os.path.join(HERE, "deflate_golden.json"), "w"), indent=0)
+    json.dump({"checksums": sums, "inflate_kat": kats, "corrupt": corrupt,
+               "corrupt_source": {"kind": "text", "size": 20000, "seed": 3, "level": 6}},
+              open(os.path.join(HERE, "inflate_golden.json"), "w"), indent=0)
+    print(len(deflate_cases), "deflate cases,", len(kats), "inflate KATs")
+
+
+if __name__ == "__main__":
+    main()

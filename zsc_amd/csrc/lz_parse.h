@@ -19,7 +19,7 @@
  *     failures of a batch are discarded by the ballot, 64 at a time.
  *
  * Positions are absolute; the reference's window slides are tracked as the
- * number `base` (see oracle/zsc_oracle.c, same formulation, pinned against the
+ * number `base` (the formulation the CPU checker under oracle/ pins against the
  * reference).  No hash table is updated while parsing, so the positions covered
  * by an emitted match cost nothing.
  */

@@ -49,6 +49,7 @@ typedef struct {
     uint64_t in_off;    /* byte offset of the buffer in the batch input */
     uint64_t out_off;   /* byte offset of its stream in the batch output (4-byte aligned) */
     uint64_t sym_off;   /* first symbol slot */
+    uint64_t rank_off;  /* first entry of the buffer in the rank array */
     uint32_t in_len;
     uint32_t out_cap;
     uint32_t tile0;     /* index of its first tile */

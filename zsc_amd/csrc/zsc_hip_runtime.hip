@@ -1,0 +1,725 @@
+/*
+ * zsc_hip_runtime.hip -- kernels and host runtime of libzsc_hip.so (gfx950 only).
+ *
+ * The __global__ functions are thin: each one finds its unit of work (tile,
+ * buffer or block) and calls the wavefront code in the headers of this
+ * directory.  The host half owns HBM scratch, builds the work descriptors and
+ * enqueues the six kernels of a deflate pass on one HIP stream.
+ *
+ * Path and boundary: this file implements the batched extension declared in
+ * include/zsc_hip.h; zsc_api.c puts the reference's own zsc_pub.h signatures on
+ * top of it.
+ */
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <mutex>
+#include <vector>
+
+#include "bit_emit.h"
+#include "checksum.h"
+#include "hash_sort.h"
+#include "huff_plan.h"
+#include "lz_parse.h"
+#include "zsc_dev.h"
+
+#include "zsc/zsc_conf_private.h"
+#include "zsc_hip.h"
+
+/* ------------------------------------------------------------------------ */
+/* kernels                                                                  */
+/* ------------------------------------------------------------------------ */
+
+/* kernel 0: one wavefront per buffer */
+__global__ __launch_bounds__(64) void k_checksum(const uint8_t *__restrict__ in,
+                                                 const ZdBuf *__restrict__ bufs,
+                                                 ZdResult *__restrict__ res, uint32_t nbuf)
+{
+    __shared__ CkLds lds;
+    const uint32_t b = blockIdx.x;
+    if (b >= nbuf)
+        return;
+    const ZdBuf buf = bufs[b];
+    uint32_t v = 0;
+    if (buf.wrap == 1)
+        v = ck_adler32(in + buf.in_off, buf.in_len);
+    else if (buf.wrap == 2)
+        v = ck_crc32(in + buf.in_off, buf.in_len, &lds);
+    if (threadIdx.x == 0)
+        res[b].adler = v;
+}
+
+/* kernel 1: one workgroup (HS_WAVES wavefronts) per 32 KiB tile */
+__global__ __launch_bounds__(HS_WAVES * 64) void k_hash_sort(
+    const uint8_t *__restrict__ in, const ZdBuf *__restrict__ bufs,
+    const uint32_t *__restrict__ tile_owner, uint32_t *__restrict__ sorted,
+    uint32_t *__restrict__ tmp, uint16_t *__restrict__ rank, uint16_t *__restrict__ dir,
+    uint32_t ntiles)
+{
+    __shared__ HsLds lds;
+    const uint32_t tile = blockIdx.x;
+    if (tile >= ntiles)
+        return;
+    const ZdBuf buf = bufs[tile_owner[tile]];
+    const uint32_t t = tile - buf.tile0;
+    HsTile job;
+    job.in = in + buf.in_off;
+    job.n = buf.in_len;
+    job.start = t * ZD_TILE;
+    const uint32_t owners = buf.in_len >= 3 ? buf.in_len - 2 : 0;
+    job.m = owners > job.start ? min(owners - job.start, ZD_TILE) : 0u;
+    job.sorted = sorted + (uint64_t)tile * ZD_TILE;
+    job.tmp = tmp + (uint64_t)tile * ZD_TILE;
+    job.rank = rank + buf.rank_off;
+    job.dir = (t + 1 < buf.ntiles) ? dir + (uint64_t)tile * ZD_DIR_STRIDE : nullptr;
+    const int w = (int)(threadIdx.x >> 6);
+    for (int phase = 0; phase < HS_PHASES; phase++) {
+        hash_sort_phase(job, &lds, w, phase);
+        __syncthreads();
+    }
+}
+
+/* kernel 2: one wavefront per buffer, longest buffers first */
+__global__ __launch_bounds__(64) void k_parse(const uint8_t *__restrict__ in,
+                                              const ZdBuf *__restrict__ bufs,
+                                              const uint32_t *__restrict__ order,
+                                              const uint32_t *__restrict__ sorted,
+                                              const uint16_t *__restrict__ rank,
+                                              const uint16_t *__restrict__ dir,
+                                              uint32_t *__restrict__ syms,
+                                              ZdBlockRec *__restrict__ recs,
+                                              ZdParseOut *__restrict__ pout,
+                                              const ZdLevel cfg, uint32_t nbuf)
+{
+    __shared__ LzLds lds;
+    if (blockIdx.x >= nbuf)
+        return;
+    const uint32_t b = order[blockIdx.x];
+    const ZdBuf buf = bufs[b];
+    LzJob job;
+    job.in = in + buf.in_off;
+    job.n = buf.in_len;
+    job.sorted = sorted + (uint64_t)buf.tile0 * ZD_TILE;
+    job.rank = rank + buf.rank_off;
+    job.dir = dir + (uint64_t)buf.tile0 * ZD_DIR_STRIDE;
+    job.syms = syms + buf.sym_off;
+    job.blocks = recs + buf.blk0;
+    job.out = pout + b;
+    job.cfg = cfg;
+    job.strategy = buf.strategy;
+    lz_parse_lazy(job, &lds);
+}
+
+/* kernel 3: one wavefront per (possible) block */
+__global__ __launch_bounds__(64) void k_huff_plan(const ZdBuf *__restrict__ bufs,
+                                                  const uint32_t *__restrict__ blk_owner,
+                                                  const uint32_t *__restrict__ syms,
+                                                  const ZdBlockRec *__restrict__ recs,
+                                                  const ZdParseOut *__restrict__ pout,
+                                                  ZdBlockPlan *__restrict__ plans, uint32_t nslots)
+{
+    __shared__ HpLds lds;
+    const uint32_t slot = blockIdx.x;
+    if (slot >= nslots)
+        return;
+    const uint32_t b = blk_owner[slot];
+    const ZdBuf buf = bufs[b];
+    if (slot - buf.blk0 >= pout[b].nblocks)
+        return;
+    const ZdBlockRec *rec = &recs[slot];
+    huff_plan_block(syms + buf.sym_off + rec->sym_begin, rec, buf.strategy, &plans[slot], &lds);
+}
+
+/* kernel 4a: one thread per buffer */
+__global__ __launch_bounds__(64) void k_layout(const ZdBuf *__restrict__ bufs,
+                                               const ZdParseOut *__restrict__ pout,
+                                               const ZdBlockRec *__restrict__ recs,
+                                               ZdBlockPlan *__restrict__ plans,
+                                               ZdResult *__restrict__ res,
+                                               uint8_t *__restrict__ out, uint32_t nbuf)
+{
+    const uint32_t b = blockIdx.x * blockDim.x + threadIdx.x;
+    if (b >= nbuf)
+        return;
+    layout_buffer(&bufs[b], &pout[b], recs + bufs[b].blk0, plans + bufs[b].blk0, &res[b],
+                  out + bufs[b].out_off);
+}
+
+/* kernel 4b: one wavefront per block */
+__global__ __launch_bounds__(64) void k_emit(const uint8_t *__restrict__ in,
+                                             const ZdBuf *__restrict__ bufs,
+                                             const uint32_t *__restrict__ blk_owner,
+                                             const uint32_t *__restrict__ syms,
+                                             const ZdBlockRec *__restrict__ recs,
+                                             const ZdParseOut *__restrict__ pout,
+                                             const ZdBlockPlan *__restrict__ plans,
+                                             uint8_t *__restrict__ out, uint32_t nslots)
+{
+    __shared__ BeLds lds;
+    const uint32_t slot = blockIdx.x;
+    if (slot >= nslots)
+        return;
+    const uint32_t b = blk_owner[slot];
+    const ZdBuf buf = bufs[b];
+    if (slot - buf.blk0 >= pout[b].nblocks)
+        return;
+    const ZdBlockRec *rec = &recs[slot];
+    emit_block(in + buf.in_off, syms + buf.sym_off + rec->sym_begin, rec, &plans[slot],
+               (uint32_t *)(out + buf.out_off), &lds);
+}
+
+/* ------------------------------------------------------------------------ */
+/* host runtime                                                             */
+/* ------------------------------------------------------------------------ */
+
+namespace {
+
+const ZdLevel kLevels[10] = {
+    {0, 0, 0, 0, 0},         {4, 4, 8, 4, 0},       {4, 5, 16, 8, 0},     {4, 6, 32, 32, 0},
+    {4, 4, 16, 16, 1},       {8, 16, 32, 32, 1},    {8, 16, 128, 128, 1}, {8, 32, 128, 256, 1},
+    {32, 128, 258, 1024, 1}, {32, 258, 258, 4096, 1}};
+
+std::once_flag g_init_once;
+int g_init_status = Z_STREAM_ERROR;
+char g_device_info[256] = "uninitialised";
+
+#define HIP_TRY(expr, fail)                                                              \
+    do {                                                                                 \
+        hipError_t _e = (expr);                                                          \
+        if (_e != hipSuccess) {                                                          \
+            ZSC_WARN2("zsc_hip: %s failed: %s", #expr, hipGetErrorString(_e));           \
+            fail;                                                                        \
+        }                                                                                \
+    } while (0)
+
+void do_init(int ordinal)
+{
+    int count = 0;
+    if (hipGetDeviceCount(&count) != hipSuccess || count == 0) {
+        ZSC_WARN("zsc_hip: no HIP device is visible; this library has no CPU path.");
+        g_init_status = Z_STREAM_ERROR;
+        return;
+    }
+    if (ordinal < 0) {
+        const char *lr = getenv("LOCAL_RANK");
+        ordinal = lr ? atoi(lr) % count : 0;
+    }
+    if (hipSetDevice(ordinal) != hipSuccess) {
+        ZSC_WARN1("zsc_hip: cannot select device %d.", ordinal);
+        g_init_status = Z_STREAM_ERROR;
+        return;
+    }
+    hipDeviceProp_t prop;
+    if (hipGetDeviceProperties(&prop, ordinal) != hipSuccess) {
+        g_init_status = Z_STREAM_ERROR;
+        return;
+    }
+    snprintf(g_device_info, sizeof g_device_info, "%s | %s | %d CUs | %.1f GiB", prop.name,
+             prop.gcnArchName, prop.multiProcessorCount,
+             (double)prop.totalGlobalMem / (1024.0 * 1024.0 * 1024.0));
+    if (strncmp(prop.gcnArchName, "gfx950", 6) != 0) {
+        ZSC_WARN1("zsc_hip: built for gfx950 only, found %s.", prop.gcnArchName);
+        g_init_status = Z_STREAM_ERROR;
+        return;
+    }
+    g_init_status = Z_OK;
+}
+
+struct DevBuf {
+    void *p = nullptr;
+    size_t bytes = 0;
+    bool ensure(size_t need)
+    {
+        if (need <= bytes)
+            return true;
+        if (p)
+            (void)hipFree(p);
+        p = nullptr;
+        bytes = 0;
+        if (hipMalloc(&p, need) != hipSuccess) {
+            ZSC_WARN1("zsc_hip: hipMalloc of %zu bytes failed.", need);
+            return false;
+        }
+        bytes = need;
+        return true;
+    }
+    void release()
+    {
+        if (p)
+            (void)hipFree(p);
+        p = nullptr;
+        bytes = 0;
+    }
+};
+
+/* a group of buffers that shares one set of scratch arrays */
+struct SubBatch {
+    uint32_t first = 0, count = 0; /* buffers [first, first+count) of the plan */
+    uint32_t ntiles = 0, nslots = 0;
+    uint64_t nsym_slots = 0;
+    DevBuf d_bufs, d_tile_owner, d_blk_owner, d_order;
+};
+
+} // namespace
+
+struct zsc_hip_deflate_plan {
+    uint32_t count = 0;
+    int level = 6, wrap = 1;
+    uint32_t strategy = 0;
+    std::vector<ZdBuf> bufs; /* in_off / out_off are absolute in the caller's buffers */
+    std::vector<SubBatch> subs;
+    /* scratch shared by all sub-batches (sized for the largest) */
+    DevBuf d_sorted, d_tmp_syms, d_rank, d_dir, d_recs, d_plans, d_pout;
+    DevBuf d_res; /* one ZdResult per buffer of the whole plan */
+    uint64_t rank_base_off = 0;
+    bool profile = false;
+    float times[ZSC_HIP_NKERNELS] = {0};
+    std::vector<hipEvent_t> events; /* 7 per sub-batch per profiled run */
+    size_t events_used = 0;
+    uint32_t profiled_runs = 0;
+    hipStream_t last_stream = nullptr;
+    uint64_t scratch_bytes = 0;
+};
+
+extern "C" I32 zsc_hip_init(I32 device_ordinal)
+{
+    std::call_once(g_init_once, do_init, (int)device_ordinal);
+    return g_init_status;
+}
+
+extern "C" const char *zsc_hip_device_info(void)
+{
+    (void)zsc_hip_init(-1);
+    return g_device_info;
+}
+
+/* reference deflateBoundNoStream + zsc_compress_get_max_output_size2; defined in zsc_api.c */
+extern "C" ZlibReturn zsc_compress_get_max_output_size2(U32, U32, I32, I32, I32, U32 *);
+
+static bool offloadable(I32 level, I32 window_bits, I32 mem_level, ZlibStrategy strategy, int *wrap)
+{
+    int wb = window_bits;
+    *wrap = 1;
+    if (wb < 0) {
+        *wrap = 0;
+        wb = -wb;
+    } else if (wb > 15) {
+        *wrap = 2;
+        wb -= 16;
+    }
+    if (level == Z_DEFAULT_COMPRESSION)
+        level = 6;
+    return wb == 15 && mem_level == 8 && level >= 4 && level <= 9 &&
+           (strategy == Z_DEFAULT_STRATEGY || strategy == Z_FILTERED || strategy == Z_FIXED);
+}
+
+extern "C" ZlibReturn zsc_hip_deflate_plan_layout(U32 count, const U32 *source_lens, I32 level,
+                                                  I32 window_bits, I32 mem_level,
+                                                  uint64_t *in_offsets, uint64_t *out_offsets,
+                                                  U32 *out_caps, uint64_t *in_bytes,
+                                                  uint64_t *out_bytes)
+{
+    ZSC_ASSERT(source_lens != Z_NULL);
+    ZSC_ASSERT(in_offsets != Z_NULL);
+    ZSC_ASSERT(out_offsets != Z_NULL);
+    ZSC_ASSERT(out_caps != Z_NULL);
+    uint64_t io = 0, oo = 0;
+    for (U32 i = 0; i < count; i++) {
+        U32 cap = 0;
+        const U32 n = source_lens[i];
+        ZlibReturn rc = zsc_compress_get_max_output_size2(n, n ? n : 1, level, window_bits,
+                                                          mem_level, &cap);
+        if (rc != Z_OK)
+            return rc;
+        in_offsets[i] = io;
+        out_offsets[i] = oo;
+        out_caps[i] = cap;
+        io += ((uint64_t)n + 15u) & ~15ull;
+        oo += ((uint64_t)cap + 16u + 15u) & ~15ull;
+    }
+    if (in_bytes)
+        *in_bytes = io + 64;
+    if (out_bytes)
+        *out_bytes = oo + 64;
+    return Z_OK;
+}
+
+extern "C" ZlibReturn zsc_hip_deflate_plan_create(zsc_hip_deflate_plan **plan_out, U32 count,
+                                                  const U32 *source_lens,
+                                                  const uint64_t *in_offsets,
+                                                  const uint64_t *out_offsets, const U32 *out_caps,
+                                                  I32 level, I32 window_bits, I32 mem_level,
+                                                  ZlibStrategy strategy)
+{
+    ZSC_ASSERT(plan_out != Z_NULL);
+    *plan_out = nullptr;
+    if (zsc_hip_init(-1) != Z_OK)
+        return Z_STREAM_ERROR;
+    int wrap = 1;
+    if (!offloadable(level, window_bits, mem_level, strategy, &wrap)) {
+        ZSC_WARN4("zsc_hip: level %d / window_bits %d / mem_level %d / strategy %d is not "
+                  "offloaded to the GPU yet (DESIGN.md, out of scope).",
+                  level, window_bits, mem_level, (int)strategy);
+        return Z_STREAM_ERROR;
+    }
+    if (level == Z_DEFAULT_COMPRESSION)
+        level = 6;
+    auto *pl = new zsc_hip_deflate_plan();
+    pl->count = count;
+    pl->level = level;
+    pl->wrap = wrap;
+    pl->strategy = (uint32_t)strategy;
+    pl->bufs.resize(count);
+
+    uint64_t sub_limit = 4096ull << 20; /* input bytes per sub-batch */
+    if (const char *e = getenv("ZSC_HIP_SUBBATCH_MB"))
+        sub_limit = (uint64_t)atoll(e) << 20;
+    if (sub_limit < (1ull << 20))
+        sub_limit = 1ull << 20;
+
+    /* cut into sub-batches and number tiles / block slots / symbol slots inside each */
+    uint64_t max_tiles = 0, max_slots = 0, max_syms = 0, max_rank_span = 0, max_count = 0;
+    uint32_t i = 0;
+    while (i < count) {
+        SubBatch sb;
+        sb.first = i;
+        uint64_t bytes = 0;
+        while (i < count && (sb.count == 0 || bytes + source_lens[i] <= sub_limit)) {
+            const uint32_t n = source_lens[i];
+            if (in_offsets[i] & 15u || out_offsets[i] & 15u) {
+                ZSC_WARN1("zsc_hip: buffer %u is not 16-byte aligned in the batch.", i);
+                delete pl;
+                return Z_STREAM_ERROR;
+            }
+            ZdBuf &b = pl->bufs[i];
+            memset(&b, 0, sizeof b);
+            b.in_off = in_offsets[i];
+            b.out_off = out_offsets[i];
+            b.in_len = n;
+            b.out_cap = out_caps[i];
+            b.ntiles = n == 0 ? 1u : (n + ZD_TILE - 1) / ZD_TILE;
+            b.tile0 = sb.ntiles;
+            b.max_blocks = n / ZD_SYM_CAP + 2;
+            b.blk0 = sb.nslots;
+            b.sym_off = sb.nsym_slots;
+            b.rank_off = sb.nsym_slots; /* one u16 per (padded) input position */
+            b.level = (uint32_t)level;
+            b.wrap = (uint32_t)wrap;
+            b.strategy = (uint32_t)strategy;
+            sb.ntiles += b.ntiles;
+            sb.nslots += b.max_blocks;
+            sb.nsym_slots += ((uint64_t)n + 64u) & ~63ull;
+            bytes += n;
+            sb.count++;
+            i++;
+        }
+        max_tiles = std::max<uint64_t>(max_tiles, sb.ntiles);
+        max_slots = std::max<uint64_t>(max_slots, sb.nslots);
+        max_syms = std::max<uint64_t>(max_syms, sb.nsym_slots);
+        max_rank_span = std::max<uint64_t>(max_rank_span, sb.nsym_slots + 64);
+        max_count = std::max<uint64_t>(max_count, sb.count);
+        pl->subs.push_back(std::move(sb));
+    }
+
+    /* per-sub-batch descriptor arrays */
+    for (SubBatch &sb : pl->subs) {
+        std::vector<uint32_t> tile_owner(sb.ntiles), blk_owner(sb.nslots), order(sb.count);
+        for (uint32_t k = 0; k < sb.count; k++) {
+            const ZdBuf &b = pl->bufs[sb.first + k];
+            for (uint32_t t = 0; t < b.ntiles; t++)
+                tile_owner[b.tile0 + t] = k;
+            for (uint32_t s = 0; s < b.max_blocks; s++)
+                blk_owner[b.blk0 + s] = k;
+            order[k] = k;
+        }
+        std::stable_sort(order.begin(), order.end(), [&](uint32_t a, uint32_t c) {
+            return pl->bufs[sb.first + a].in_len > pl->bufs[sb.first + c].in_len;
+        });
+        bool ok = sb.d_bufs.ensure(sizeof(ZdBuf) * sb.count) &&
+                  sb.d_tile_owner.ensure(4ull * std::max(1u, sb.ntiles)) &&
+                  sb.d_blk_owner.ensure(4ull * std::max(1u, sb.nslots)) &&
+                  sb.d_order.ensure(4ull * sb.count);
+        if (!ok) {
+            zsc_hip_deflate_plan_destroy(pl);
+            return Z_MEM_ERROR;
+        }
+        HIP_TRY(hipMemcpy(sb.d_bufs.p, &pl->bufs[sb.first], sizeof(ZdBuf) * sb.count,
+                          hipMemcpyHostToDevice),
+                { zsc_hip_deflate_plan_destroy(pl); return Z_MEM_ERROR; });
+        HIP_TRY(hipMemcpy(sb.d_tile_owner.p, tile_owner.data(), 4ull * sb.ntiles,
+                          hipMemcpyHostToDevice),
+                { zsc_hip_deflate_plan_destroy(pl); return Z_MEM_ERROR; });
+        HIP_TRY(hipMemcpy(sb.d_blk_owner.p, blk_owner.data(), 4ull * sb.nslots,
+                          hipMemcpyHostToDevice),
+                { zsc_hip_deflate_plan_destroy(pl); return Z_MEM_ERROR; });
+        HIP_TRY(hipMemcpy(sb.d_order.p, order.data(), 4ull * sb.count, hipMemcpyHostToDevice),
+                { zsc_hip_deflate_plan_destroy(pl); return Z_MEM_ERROR; });
+        pl->scratch_bytes += sb.d_bufs.bytes + sb.d_tile_owner.bytes + sb.d_blk_owner.bytes +
+                             sb.d_order.bytes;
+    }
+
+    /* shared scratch: sorted (4 B/position), tmp aliased with the symbol stream
+     * (4 B/position, tmp is dead once the sort kernel ends), rank (2 B/position,
+     * indexed by input offset), dir (2 B/position), block records + plans */
+    const uint64_t tile_words = max_tiles * ZD_TILE;
+    bool ok = pl->d_sorted.ensure(tile_words * 4) &&
+              pl->d_tmp_syms.ensure(std::max<uint64_t>(tile_words, max_syms) * 4) &&
+              pl->d_rank.ensure(max_rank_span * 2) &&
+              pl->d_dir.ensure(max_tiles * ZD_DIR_STRIDE * 2) &&
+              pl->d_recs.ensure(max_slots * sizeof(ZdBlockRec)) &&
+              pl->d_plans.ensure(max_slots * sizeof(ZdBlockPlan)) &&
+              pl->d_pout.ensure(max_count * sizeof(ZdParseOut)) &&
+              pl->d_res.ensure((uint64_t)std::max(1u, count) * sizeof(ZdResult));
+    if (!ok) {
+        zsc_hip_deflate_plan_destroy(pl);
+        return Z_MEM_ERROR;
+    }
+    pl->scratch_bytes += pl->d_sorted.bytes + pl->d_tmp_syms.bytes + pl->d_rank.bytes +
+                         pl->d_dir.bytes + pl->d_recs.bytes + pl->d_plans.bytes +
+                         pl->d_pout.bytes + pl->d_res.bytes;
+    *plan_out = pl;
+    return Z_OK;
+}
+
+extern "C" void zsc_hip_deflate_plan_profile(zsc_hip_deflate_plan *plan, I32 enable)
+{
+    ZSC_ASSERT(plan != Z_NULL);
+    plan->profile = enable != 0;
+    plan->events_used = 0; /* a new measurement window starts */
+    plan->profiled_runs = 0;
+}
+
+extern "C" ZlibReturn zsc_hip_deflate_plan_run(zsc_hip_deflate_plan *pl, const void *d_input,
+                                               void *d_output, void *hip_stream)
+{
+    ZSC_ASSERT(pl != Z_NULL);
+    ZSC_ASSERT(d_input != Z_NULL);
+    ZSC_ASSERT(d_output != Z_NULL);
+    hipStream_t st = (hipStream_t)hip_stream;
+    pl->last_stream = st;
+    const uint8_t *in = (const uint8_t *)d_input;
+    uint8_t *out = (uint8_t *)d_output;
+    const ZdLevel cfg = kLevels[pl->level];
+
+    const size_t nev = pl->events_used + pl->subs.size() * 7;
+    if (pl->profile) {
+        while (pl->events.size() < nev) {
+            hipEvent_t e;
+            HIP_TRY(hipEventCreate(&e), return Z_MEM_ERROR);
+            pl->events.push_back(e);
+        }
+        pl->profiled_runs++;
+    }
+    auto mark = [&]() {
+        if (pl->profile)
+            (void)hipEventRecord(pl->events[pl->events_used++], st);
+    };
+
+    for (SubBatch &sb : pl->subs) {
+        const ZdBuf *bufs = (const ZdBuf *)sb.d_bufs.p;
+        ZdResult *res = (ZdResult *)pl->d_res.p + sb.first;
+        uint32_t *sorted = (uint32_t *)pl->d_sorted.p;
+        uint32_t *tmp_syms = (uint32_t *)pl->d_tmp_syms.p;
+        uint16_t *rank = (uint16_t *)pl->d_rank.p;
+        uint16_t *dir = (uint16_t *)pl->d_dir.p;
+        ZdBlockRec *recs = (ZdBlockRec *)pl->d_recs.p;
+        ZdBlockPlan *plans = (ZdBlockPlan *)pl->d_plans.p;
+        ZdParseOut *pout = (ZdParseOut *)pl->d_pout.p;
+
+        mark();
+        hipLaunchKernelGGL(k_checksum, dim3(sb.count), dim3(64), 0, st, in, bufs, res, sb.count);
+        mark();
+        hipLaunchKernelGGL(k_hash_sort, dim3(sb.ntiles), dim3(HS_WAVES * 64), 0, st, in, bufs,
+                           (const uint32_t *)sb.d_tile_owner.p, sorted, tmp_syms, rank, dir,
+                           sb.ntiles);
+        mark();
+        hipLaunchKernelGGL(k_parse, dim3(sb.count), dim3(64), 0, st, in, bufs,
+                           (const uint32_t *)sb.d_order.p, (const uint32_t *)sorted,
+                           (const uint16_t *)rank, (const uint16_t *)dir, tmp_syms, recs, pout,
+                           cfg, sb.count);
+        mark();
+        hipLaunchKernelGGL(k_huff_plan, dim3(sb.nslots), dim3(64), 0, st, bufs,
+                           (const uint32_t *)sb.d_blk_owner.p, (const uint32_t *)tmp_syms,
+                           (const ZdBlockRec *)recs, (const ZdParseOut *)pout, plans, sb.nslots);
+        mark();
+        hipLaunchKernelGGL(k_layout, dim3((sb.count + 63) / 64), dim3(64), 0, st, bufs,
+                           (const ZdParseOut *)pout, (const ZdBlockRec *)recs, plans, res, out,
+                           sb.count);
+        mark();
+        hipLaunchKernelGGL(k_emit, dim3(sb.nslots), dim3(64), 0, st, in, bufs,
+                           (const uint32_t *)sb.d_blk_owner.p, (const uint32_t *)tmp_syms,
+                           (const ZdBlockRec *)recs, (const ZdParseOut *)pout,
+                           (const ZdBlockPlan *)plans, out, sb.nslots);
+        mark();
+    }
+    HIP_TRY(hipGetLastError(), return Z_STREAM_ERROR);
+    return Z_OK;
+}
+
+extern "C" ZlibReturn zsc_hip_deflate_plan_results(zsc_hip_deflate_plan *pl, U32 *dest_lens,
+                                                   I32 *statuses)
+{
+    ZSC_ASSERT(pl != Z_NULL);
+    HIP_TRY(hipStreamSynchronize(pl->last_stream), return Z_STREAM_ERROR);
+    std::vector<ZdResult> res(pl->count);
+    if (pl->count)
+        HIP_TRY(hipMemcpy(res.data(), pl->d_res.p, sizeof(ZdResult) * pl->count,
+                          hipMemcpyDeviceToHost),
+                return Z_STREAM_ERROR);
+    for (uint32_t i = 0; i < pl->count; i++) {
+        if (dest_lens)
+            dest_lens[i] = res[i].out_len;
+        if (statuses)
+            statuses[i] = res[i].status;
+    }
+    if (pl->profile && pl->profiled_runs) {
+        /* mean per run over every run since profiling was switched on */
+        for (int k = 0; k < ZSC_HIP_NKERNELS; k++)
+            pl->times[k] = 0.f;
+        const size_t per_run = pl->subs.size() * 7;
+        for (uint32_t r = 0; r < pl->profiled_runs; r++) {
+            const size_t e0 = (size_t)r * per_run;
+            for (size_t s = 0; s < pl->subs.size(); s++) {
+                for (int k = 0; k < 6; k++) {
+                    float ms = 0.f;
+                    (void)hipEventElapsedTime(&ms, pl->events[e0 + s * 7 + k],
+                                              pl->events[e0 + s * 7 + k + 1]);
+                    pl->times[k] += ms;
+                }
+            }
+            float ms = 0.f;
+            (void)hipEventElapsedTime(&ms, pl->events[e0], pl->events[e0 + per_run - 1]);
+            pl->times[6] += ms;
+        }
+        for (int k = 0; k < ZSC_HIP_NKERNELS; k++)
+            pl->times[k] /= (float)pl->profiled_runs;
+    }
+    return Z_OK;
+}
+
+extern "C" ZlibReturn zsc_hip_deflate_plan_times(zsc_hip_deflate_plan *pl, float *ms_out)
+{
+    ZSC_ASSERT(pl != Z_NULL);
+    ZSC_ASSERT(ms_out != Z_NULL);
+    for (int k = 0; k < ZSC_HIP_NKERNELS; k++)
+        ms_out[k] = pl->times[k];
+    return pl->profile ? Z_OK : Z_STREAM_ERROR;
+}
+
+extern "C" uint64_t zsc_hip_deflate_plan_scratch_bytes(const zsc_hip_deflate_plan *pl)
+{
+    return pl ? pl->scratch_bytes : 0;
+}
+
+extern "C" void zsc_hip_deflate_plan_destroy(zsc_hip_deflate_plan *pl)
+{
+    if (!pl)
+        return;
+    for (SubBatch &sb : pl->subs) {
+        sb.d_bufs.release();
+        sb.d_tile_owner.release();
+        sb.d_blk_owner.release();
+        sb.d_order.release();
+    }
+    pl->d_sorted.release();
+    pl->d_tmp_syms.release();
+    pl->d_rank.release();
+    pl->d_dir.release();
+    pl->d_recs.release();
+    pl->d_plans.release();
+    pl->d_pout.release();
+    pl->d_res.release();
+    for (hipEvent_t e : pl->events)
+        (void)hipEventDestroy(e);
+    delete pl;
+}
+
+/* host-pointer batch: stage through one pair of device buffers */
+extern "C" ZlibReturn zsc_hip_compress_batch(U32 count, const U8 *const *sources,
+                                             const U32 *source_lens, U8 *const *dests,
+                                             U32 *dest_lens, I32 *statuses, I32 level,
+                                             I32 window_bits, I32 mem_level,
+                                             ZlibStrategy strategy)
+{
+    ZSC_ASSERT(sources != Z_NULL);
+    ZSC_ASSERT(source_lens != Z_NULL);
+    ZSC_ASSERT(dests != Z_NULL);
+    ZSC_ASSERT(dest_lens != Z_NULL);
+    if (count == 0)
+        return Z_OK;
+    std::vector<uint64_t> in_off(count), out_off(count);
+    std::vector<U32> caps(count), lens(count);
+    std::vector<I32> stat(count);
+    uint64_t in_bytes = 0, out_bytes = 0;
+    ZlibReturn rc = zsc_hip_deflate_plan_layout(count, source_lens, level, window_bits, mem_level,
+                                                in_off.data(), out_off.data(), caps.data(),
+                                                &in_bytes, &out_bytes);
+    if (rc != Z_OK)
+        return rc;
+    zsc_hip_deflate_plan *pl = nullptr;
+    rc = zsc_hip_deflate_plan_create(&pl, count, source_lens, in_off.data(), out_off.data(),
+                                     caps.data(), level, window_bits, mem_level, strategy);
+    if (rc != Z_OK)
+        return rc;
+    DevBuf d_in, d_out;
+    if (!d_in.ensure(in_bytes) || !d_out.ensure(out_bytes)) {
+        d_in.release();
+        d_out.release();
+        zsc_hip_deflate_plan_destroy(pl);
+        return Z_MEM_ERROR;
+    }
+    rc = Z_OK;
+    for (U32 i = 0; i < count && rc == Z_OK; i++) {
+        ZSC_ASSERT(sources[i] != Z_NULL);
+        if (source_lens[i] &&
+            hipMemcpy((uint8_t *)d_in.p + in_off[i], sources[i], source_lens[i],
+                      hipMemcpyHostToDevice) != hipSuccess)
+            rc = Z_STREAM_ERROR;
+    }
+    if (rc == Z_OK)
+        rc = zsc_hip_deflate_plan_run(pl, d_in.p, d_out.p, nullptr);
+    if (rc == Z_OK)
+        rc = zsc_hip_deflate_plan_results(pl, lens.data(), stat.data());
+    for (U32 i = 0; i < count && rc == Z_OK; i++) {
+        ZSC_ASSERT(dests[i] != Z_NULL);
+        const U32 cap = dest_lens[i];
+        I32 s = stat[i];
+        U32 give = lens[i];
+        if (s == Z_OK && give > cap) {
+            /* the reference hands out dest in slices and fails once it is used up:
+             * the caller keeps the prefix that fitted (src/zsc_compress.c:126-140) */
+            give = cap;
+            s = Z_BUF_ERROR;
+        } else if (s != Z_OK) {
+            give = 0;
+        }
+        if (give && hipMemcpy(dests[i], (uint8_t *)d_out.p + out_off[i], give,
+                              hipMemcpyDeviceToHost) != hipSuccess)
+            rc = Z_STREAM_ERROR;
+        dest_lens[i] = give;
+        if (statuses)
+            statuses[i] = s;
+    }
+    d_in.release();
+    d_out.release();
+    zsc_hip_deflate_plan_destroy(pl);
+    return rc;
+}
+
+extern "C" ZlibReturn zsc_hip_uncompress_batch(U32 count, const U8 *const *sources,
+                                               U32 *source_lens, U8 *const *dests,
+                                               U32 *dest_lens, I32 *statuses, I32 window_bits)
+{
+    (void)count;
+    (void)sources;
+    (void)source_lens;
+    (void)dests;
+    (void)dest_lens;
+    (void)statuses;
+    (void)window_bits;
+    ZSC_WARN("zsc_hip: the inflate kernels are not built yet (DESIGN.md, next).");
+    return Z_STREAM_ERROR;
+}
