@@ -46,6 +46,8 @@ def cpu_baseline(level: int, seconds_budget: float = 20.0):
         cores = len(os.sched_getaffinity(0))
     except Exception:
         pass
+    # a one-GPU box owns a 16-core share of the host (more threads would only oversubscribe it)
+    cores = max(1, min(cores, int(os.environ.get("ZSC_BENCH_CPU_THREADS", "16"))))
     kind = "reference" if Reference.available() else "port"
     sets = [corpus.canterbury_like(s) for s in range(2)]
     set_bytes = sum(len(b) for _, b in sets[0])

@@ -32,6 +32,15 @@ def build_library() -> None:
 
 
 def _load() -> C.CDLL:
+    # PyTorch-ROCm wheels bundle their own libamdhip64 (SONAME libamdhip64.so.7, the same
+    # as /opt/rocm's).  Two HIP runtimes in one process cannot both own the GPU, so when
+    # torch is installed it is imported FIRST: the loader then resolves libzsc_hip.so's
+    # NEEDED libamdhip64.so.7 to the copy torch already mapped, and tensors, streams and
+    # our kernels share one runtime.  Without torch the system ROCm runtime is used.
+    try:
+        import torch  # noqa: F401
+    except Exception:
+        pass
     if not os.path.exists(lib_path):
         raise ImportError(
             f"{lib_path} is missing: run `python -c 'import __graft_entry__ as g; g.build()'` "
