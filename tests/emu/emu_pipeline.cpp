@@ -29,7 +29,7 @@ struct EmuChains {
     std::vector<uint8_t> in;
     uint32_t n, ntiles;
     std::vector<uint32_t> sorted, tmp;
-    std::vector<uint16_t> rank, dir;
+    std::vector<uint16_t> rank, dir, hib;
 };
 
 static void build_chains(EmuChains &c, const uint8_t *src, uint32_t n)
@@ -42,6 +42,7 @@ static void build_chains(EmuChains &c, const uint8_t *src, uint32_t n)
     c.tmp.assign((size_t)c.ntiles * ZD_TILE, 0xdeadbeef);
     c.rank.assign((size_t)n + 64, 0xdead);
     c.dir.assign((size_t)c.ntiles * ZD_DIR_STRIDE, 0xdead);
+    c.hib.assign((size_t)n + 64, 0xdead);
     uint32_t owners = n >= 3 ? n - 2 : 0; /* positions 0..n-3 own a 3-byte string */
     for (uint32_t t = 0; t < c.ntiles; t++) {
         HsTile tile;
@@ -53,10 +54,24 @@ static void build_chains(EmuChains &c, const uint8_t *src, uint32_t n)
         tile.tmp = c.tmp.data() + (size_t)t * ZD_TILE;
         tile.rank = c.rank.data();
         tile.dir = (t + 1 < c.ntiles) ? c.dir.data() + (size_t)t * ZD_DIR_STRIDE : nullptr;
+        tile.dir_prev = nullptr;
+        tile.hib = nullptr;
         HsLds lds;
         for (int ph = 0; ph < HS_PHASES; ph++)
             for (int w = 0; w < HS_WAVES; w++)
                 hash_sort_phase(tile, &lds, w, ph);
+    }
+    for (uint32_t t = 1; t < c.ntiles; t++) { /* kernel 1b */
+        HsTile tile;
+        memset(&tile, 0, sizeof tile);
+        tile.in = c.in.data();
+        tile.n = n;
+        tile.start = t * ZD_TILE;
+        tile.m = owners > tile.start ? (owners - tile.start < ZD_TILE ? owners - tile.start : ZD_TILE) : 0;
+        tile.dir_prev = c.dir.data() + (size_t)(t - 1) * ZD_DIR_STRIDE;
+        tile.hib = c.hib.data();
+        for (int w = 0; w < HS_WAVES; w++)
+            hs_link_prev(tile, w);
     }
 }
 
@@ -84,7 +99,7 @@ extern "C" int emu_parse(const uint8_t *src, uint32_t n, int level, int strategy
     job.n = n;
     job.sorted = c.sorted.data();
     job.rank = c.rank.data();
-    job.dir = c.dir.data();
+    job.hib = c.hib.data();
     job.syms = syms;
     job.blocks = blocks;
     job.out = &out;
@@ -132,7 +147,7 @@ extern "C" int emu_compress(const uint8_t *src, uint32_t n, int level, int wrap,
     job.n = n;
     job.sorted = c.sorted.data();
     job.rank = c.rank.data();
-    job.dir = c.dir.data();
+    job.hib = c.hib.data();
     job.syms = syms.data();
     job.blocks = recs.data();
     job.out = &po;

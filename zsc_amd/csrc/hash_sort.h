@@ -48,6 +48,8 @@ typedef struct {
     uint32_t *tmp;      /* TILE entries */
     uint16_t *rank;     /* per position of the buffer */
     uint16_t *dir;      /* DIR_STRIDE entries, or null when no later tile will look back */
+    const uint16_t *dir_prev; /* directory of the previous tile of the same buffer, or null */
+    uint16_t *hib;      /* per position of the buffer: last sorted index of its bucket in the previous tile */
 } HsTile;
 
 /* UPDATE_HASH over three bytes, reference src/deflate.c:174-175 */
@@ -201,6 +203,26 @@ DEV void hs_directory(const HsTile &t, int w)
             int32_t hh = s + LANE;
             if (hh <= 32768)
                 t.dir[hh] = (uint16_t)t.m;
+        }
+    }
+}
+
+/* kernel 1b (after every tile of the batch has its directory): for each position of
+ * this tile, where its hash bucket ends in the PREVIOUS tile's sorted array.  With
+ * rank[] this makes both halves of a position's chain addressable from two
+ * sequentially readable arrays -- the parser never does a dependent table lookup. */
+DEV void hs_link_prev(const HsTile &t, int w)
+{
+    if (!t.dir_prev)
+        return;
+    for (uint32_t s = (uint32_t)w * WAVE; s < t.m; s += HS_WAVES * WAVE) {
+        FOR_LANES
+        {
+            uint32_t i = s + (uint32_t)LANE;
+            if (i < t.m) {
+                uint32_t h = hs_hash3(t.in, t.start + i, t.n);
+                t.hib[t.start + i] = (uint16_t)(t.dir_prev[h + 1] - 1u); /* 0xffff: bucket empty from the start */
+            }
         }
     }
 }

@@ -29,17 +29,21 @@
 #include "wave.h"
 #include "zsc_dev.h"
 
+#define LZ_PR 512u /* positions covered by the rank/hib look-ahead ring */
+
 typedef struct {
     uint8_t ring[ZD_RING + 512]; /* sliding window; first 16 bytes mirrored after the end, rest slack for masked over-reads */
     uint32_t stage[WAVE];       /* symbols waiting for a coalesced store */
+    uint16_t prank[LZ_PR];      /* rank[] of the next few hundred positions */
+    uint16_t phib[LZ_PR];       /* hib[] of the same positions */
 } LzLds;
 
 typedef struct {
     const uint8_t *in;      /* this buffer */
     uint32_t n;
     const uint32_t *sorted; /* tile 0 of this buffer; tile t at + t*ZD_TILE */
-    const uint16_t *rank;   /* this buffer */
-    const uint16_t *dir;    /* tile 0 of this buffer; tile t at + t*ZD_DIR_STRIDE */
+    const uint16_t *rank;   /* this buffer: index of a position in its tile's sorted array */
+    const uint16_t *hib;    /* this buffer: last index of the position's bucket in the previous tile */
     uint32_t *syms;         /* this buffer's symbol slots */
     ZdBlockRec *blocks;     /* this buffer's block records */
     ZdParseOut *out;
@@ -55,6 +59,7 @@ typedef struct {
     uint32_t data_end;  /* end of the data the reference's window would hold */
     uint32_t nsyms, nstaged;
     uint32_t nblocks, blk_sym0, blk_in0;
+    uint32_t pr_hi;     /* rank/hib are staged in LDS for positions below this */
 } LzState;
 
 DEV uint32_t lz_ridx(const LzState &st, uint32_t pos)
@@ -182,130 +187,163 @@ DEV uint32_t lz_lcp(const LzLds *lds, const LzState &st, uint32_t q, uint32_t p,
     return len < cap ? len : cap;
 }
 
-/* longest_match over the sorted runs.  Returns 0 when the reference would not have
- * called longest_match at all (no live chain head, src/deflate.c:2027-2028),
- * otherwise the value longest_match returns; *where as in s->match_start. */
-DEV uint32_t lz_search(const LzJob &job, const LzLds *lds, const LzState &st, uint32_t p,
-                       uint32_t prev_len, uint32_t *where)
+/* stage rank[]/hib[] of the positions ahead of p in LDS (64 per step, coalesced) */
+DEV void lz_ensure_ranks(const LzJob &job, LzLds *lds, LzState &st, uint32_t p)
 {
-    const uint32_t look = st.data_end - p;
-    const uint32_t tile = p >> 15;
-    const uint32_t rp = lz_ridx(st, p);
-    const uint32_t w0 = ld_u32(&lds->ring[rp]);
-    const uint32_t h = (((w0 & 0xff) << 10) ^ (((w0 >> 8) & 0xff) << 5) ^ ((w0 >> 16) & 0xff)) & ZD_HASH_MASK;
-    const uint32_t s01 = w0 & 0xffff;
-
-    uint32_t best = prev_len;
-    uint32_t budget = job.cfg.chain;
-    uint32_t nice = job.cfg.nice;
-    const uint32_t cap = look < 258u ? look : 258u;
-    if (prev_len >= job.cfg.good)
-        budget >>= 2;
-    if (nice > look)
-        nice = look;
-
-    int head_seen = 0;
-    uint32_t sb = 0; /* bytes best-1, best of the scan string */
-
-    for (int seg = 0; seg < 2; seg++) {
-        const uint32_t *run;
-        uint32_t tile_pos;
-        int32_t hi_idx, lo_idx;
-        if (seg == 0) {
-            run = job.sorted + (uint64_t)tile * ZD_TILE;
-            tile_pos = tile << 15;
-            hi_idx = (int32_t)job.rank[p] - 1;
-            lo_idx = 0;
-        } else {
-            if (tile == 0)
-                break;
-            const uint16_t *d = job.dir + (uint64_t)(tile - 1) * ZD_DIR_STRIDE;
-            run = job.sorted + (uint64_t)(tile - 1) * ZD_TILE;
-            tile_pos = (tile - 1) << 15;
-            lo_idx = (int32_t)d[h];
-            hi_idx = (int32_t)d[h + 1] - 1;
+    while (st.pr_hi < job.n && st.pr_hi < p + 384u) {
+        FOR_LANES
+        {
+            uint32_t x = st.pr_hi + (uint32_t)LANE;
+            lds->prank[x & (LZ_PR - 1)] = job.rank[x];
+            lds->phib[x & (LZ_PR - 1)] = job.hib[x];
         }
-        while (hi_idx >= lo_idx) {
-            LANEVAR(uint32_t, q);
-            LANEVAR(int, inb);   /* belongs to the chain (same hash bucket) */
-            LANEVAR(int, alive); /* and is still reachable from p */
-            FOR_LANES
-            {
-                int32_t i = hi_idx - LANE;
-                uint32_t e = i >= lo_idx ? run[i] : ZD_ENTRY_NONE;
-                LV(inb) = (e >> 16) == h;
-                LV(q) = tile_pos + (e & ZD_TILE_MASK);
-            }
-            uint64_t m_in = BALLOT(inb);
-            if (!head_seen && !(m_in & 1ull))
-                break; /* nothing of this hash in this tile */
-            FOR_LANES
-            {
-                uint32_t d = p - LV(q);
-                int near = d < ZD_MAX_DIST || (d == ZD_MAX_DIST && !head_seen && LANE == 0);
-                LV(alive) = LV(inb) && LV(q) > st.base && near;
-            }
-            uint64_t m_alive = BALLOT(alive);
-            if (!head_seen) {
-                if (!(m_alive & 1ull))
-                    return 0; /* chain head is NIL or too far: no call */
-                head_seen = 1;
-                if (best >= look)
-                    return look;
-                sb = ld_u16(&lds->ring[lz_ridx(st, p + best - 1)]);
-            }
-            const int ends_here = (m_in & ~m_alive) != 0; /* a chain member out of reach */
-
-            LANEVAR(int, pass);
-            FOR_LANES
-            {
-                int c = 0;
-                if (LV(alive)) {
-                    c = ld_u16(&lds->ring[lz_ridx(st, LV(q))]) == s01 &&
-                        ld_u16(&lds->ring[lz_ridx(st, LV(q) + best - 1)]) == sb;
-                }
-                LV(pass) = c;
-            }
-            uint64_t todo = BALLOT(pass);
-            while (todo != 0) {
-                const int j = CTZ64(todo);
-                const uint32_t qj = READLANE(q, j);
-                const uint32_t len = lz_lcp(lds, st, qj, p, cap);
-                if (len > best) {
-                    *where = qj;
-                    best = len;
-                    if (len >= nice)
-                        return best < look ? best : look;
-                    if (--budget == 0)
-                        return best < look ? best : look;
-                    sb = ld_u16(&lds->ring[lz_ridx(st, p + best - 1)]);
-                    FOR_LANES
-                    {
-                        int c = 0;
-                        if (LV(alive) && LANE > j) {
-                            c = ld_u16(&lds->ring[lz_ridx(st, LV(q))]) == s01 &&
-                                ld_u16(&lds->ring[lz_ridx(st, LV(q) + best - 1)]) == sb;
-                        }
-                        LV(pass) = c;
-                    }
-                    todo = BALLOT(pass);
-                } else {
-                    if (--budget == 0)
-                        return best < look ? best : look;
-                    todo &= todo - 1;
-                }
-            }
-            if (ends_here)
-                return best < look ? best : look;
-            if (m_in != ~0ull)
-                break; /* bucket (or tile) exhausted: continue in the older tile */
-            hi_idx -= WAVE;
-        }
+        st.pr_hi += WAVE;
     }
-    if (!head_seen)
-        return 0;
-    return best < look ? best : look;
 }
+
+/* Issue the loads for the first 64 candidates of position x in its own tile (EA)
+ * and in the previous tile (EB).  Called one search ahead, so the latency of these
+ * loads overlaps the search that runs meanwhile. */
+#define LZ_FETCH_FIRST(x, EA, EB)                                                             \
+    do {                                                                                      \
+        const uint32_t _t = (x) >> 15;                                                        \
+        const uint32_t *_ra = job.sorted + (uint64_t)_t * ZD_TILE;                            \
+        const int32_t _ha = (int32_t)lds->prank[(x) & (LZ_PR - 1)] - 1;                       \
+        const int32_t _hb = _t ? (int32_t)(int16_t)lds->phib[(x) & (LZ_PR - 1)] : -1;         \
+        FOR_LANES                                                                             \
+        {                                                                                     \
+            int32_t _ia = _ha - LANE, _ib = _hb - LANE;                                       \
+            LV(EA) = _ia >= 0 ? _ra[_ia] : ZD_ENTRY_NONE;                                     \
+            LV(EB) = _ib >= 0 ? (_ra - ZD_TILE)[_ib] : ZD_ENTRY_NONE;                         \
+        }                                                                                     \
+    } while (0)
+
+/* search context shared by the batch evaluator */
+typedef struct {
+    uint32_t p, h, s01, sb, look, cap, nice;
+    uint32_t best, budget, where;
+    int head_seen;
+} LzSearch;
+
+/* Evaluate one batch of 64 chain entries (ENT, newest first) that lie in the tile
+ * starting at TPOS.  Sets `verdict`: 0 continue with the next batch of this run,
+ * 1 this run is exhausted, 2 search finished (result in sc), 3 no live chain head. */
+#define LZ_EVAL_BATCH(ENT, TPOS, verdict)                                                     \
+    do {                                                                                      \
+        LANEVAR(uint32_t, _q);                                                                \
+        LANEVAR(int, _inb);                                                                   \
+        LANEVAR(int, _alive);                                                                 \
+        LANEVAR(int, _pass);                                                                  \
+        FOR_LANES                                                                             \
+        {                                                                                     \
+            LV(_inb) = (LV(ENT) >> 16) == sc.h;                                               \
+            LV(_q) = (TPOS) + (LV(ENT) & ZD_TILE_MASK);                                       \
+        }                                                                                     \
+        const uint64_t _m_in = BALLOT(_inb);                                                  \
+        if (!sc.head_seen && !(_m_in & 1ull)) {                                               \
+            (verdict) = 1; /* nothing of this hash in this tile */                            \
+            break;                                                                            \
+        }                                                                                     \
+        FOR_LANES                                                                             \
+        {                                                                                     \
+            uint32_t _d = sc.p - LV(_q);                                                      \
+            int _near = _d < ZD_MAX_DIST || (_d == ZD_MAX_DIST && !sc.head_seen && LANE == 0); \
+            LV(_alive) = LV(_inb) && LV(_q) > st.base && _near;                               \
+        }                                                                                     \
+        const uint64_t _m_alive = BALLOT(_alive);                                             \
+        if (!sc.head_seen) {                                                                  \
+            if (!(_m_alive & 1ull)) {                                                         \
+                (verdict) = 3; /* chain head is NIL or too far: longest_match not called */   \
+                break;                                                                        \
+            }                                                                                 \
+            sc.head_seen = 1;                                                                 \
+            if (sc.best >= sc.look) {                                                         \
+                (verdict) = 2;                                                                \
+                break;                                                                        \
+            }                                                                                 \
+            sc.sb = ld_u16(&lds->ring[lz_ridx(st, sc.p + sc.best - 1)]);                      \
+        }                                                                                     \
+        const int _ends = (_m_in & ~_m_alive) != 0; /* a chain member out of reach */         \
+        FOR_LANES                                                                             \
+        {                                                                                     \
+            int _c = 0;                                                                       \
+            if (LV(_alive)) {                                                                 \
+                _c = ld_u16(&lds->ring[lz_ridx(st, LV(_q))]) == sc.s01 &&                     \
+                     ld_u16(&lds->ring[lz_ridx(st, LV(_q) + sc.best - 1)]) == sc.sb;          \
+            }                                                                                 \
+            LV(_pass) = _c;                                                                   \
+        }                                                                                     \
+        uint64_t _todo = BALLOT(_pass);                                                       \
+        (verdict) = 0;                                                                        \
+        while (_todo != 0) {                                                                  \
+            const int _j = CTZ64(_todo);                                                      \
+            const uint32_t _qj = READLANE(_q, _j);                                            \
+            const uint32_t _len = lz_lcp(lds, st, _qj, sc.p, sc.cap);                         \
+            if (_len > sc.best) {                                                             \
+                sc.where = _qj;                                                               \
+                sc.best = _len;                                                               \
+                if (_len >= sc.nice || --sc.budget == 0) {                                    \
+                    (verdict) = 2;                                                            \
+                    break;                                                                    \
+                }                                                                             \
+                sc.sb = ld_u16(&lds->ring[lz_ridx(st, sc.p + sc.best - 1)]);                  \
+                FOR_LANES                                                                     \
+                {                                                                             \
+                    int _c = 0;                                                               \
+                    if (LV(_alive) && LANE > _j) {                                            \
+                        _c = ld_u16(&lds->ring[lz_ridx(st, LV(_q))]) == sc.s01 &&             \
+                             ld_u16(&lds->ring[lz_ridx(st, LV(_q) + sc.best - 1)]) == sc.sb;  \
+                    }                                                                         \
+                    LV(_pass) = _c;                                                           \
+                }                                                                             \
+                _todo = BALLOT(_pass);                                                        \
+            } else {                                                                          \
+                if (--sc.budget == 0) {                                                       \
+                    (verdict) = 2;                                                            \
+                    break;                                                                    \
+                }                                                                             \
+                _todo &= _todo - 1;                                                           \
+            }                                                                                 \
+        }                                                                                     \
+        if ((verdict) == 0) {                                                                 \
+            if (_ends)                                                                        \
+                (verdict) = 2;                                                                \
+            else if (_m_in != ~0ull)                                                          \
+                (verdict) = 1; /* bucket (or tile) exhausted */                               \
+        }                                                                                     \
+    } while (0)
+
+/* Walk the rest of one run (batches after the first) in groups of four batches:
+ * four independent coalesced loads are in flight together, so a long chain costs
+ * one memory round trip per 256 candidates instead of one per 64. */
+#define LZ_WALK_RUN(RUN, HI, TPOS, verdict)                                                   \
+    do {                                                                                      \
+        int32_t _hi = (HI)-WAVE;                                                              \
+        while ((verdict) == 0 && _hi >= 0) {                                                  \
+            LANEVAR(uint32_t, _g0);                                                           \
+            LANEVAR(uint32_t, _g1);                                                           \
+            LANEVAR(uint32_t, _g2);                                                           \
+            LANEVAR(uint32_t, _g3);                                                           \
+            FOR_LANES                                                                         \
+            {                                                                                 \
+                int32_t _i = _hi - LANE;                                                      \
+                LV(_g0) = _i >= 0 ? (RUN)[_i] : ZD_ENTRY_NONE;                                \
+                LV(_g1) = _i >= 64 ? (RUN)[_i - 64] : ZD_ENTRY_NONE;                          \
+                LV(_g2) = _i >= 128 ? (RUN)[_i - 128] : ZD_ENTRY_NONE;                        \
+                LV(_g3) = _i >= 192 ? (RUN)[_i - 192] : ZD_ENTRY_NONE;                        \
+            }                                                                                 \
+            LZ_EVAL_BATCH(_g0, TPOS, verdict);                                                \
+            if ((verdict) == 0)                                                               \
+                LZ_EVAL_BATCH(_g1, TPOS, verdict);                                            \
+            if ((verdict) == 0)                                                               \
+                LZ_EVAL_BATCH(_g2, TPOS, verdict);                                            \
+            if ((verdict) == 0)                                                               \
+                LZ_EVAL_BATCH(_g3, TPOS, verdict);                                            \
+            _hi -= 4 * WAVE;                                                                  \
+        }                                                                                     \
+        if ((verdict) == 0)                                                                   \
+            (verdict) = 1; /* ran off the start of the tile */                                \
+    } while (0)
 
 /* deflate_slow, reference src/deflate.c:1989-2122, flush == Z_FINISH */
 DEV void lz_parse_lazy(const LzJob &job, LzLds *lds)
@@ -316,9 +354,22 @@ DEV void lz_parse_lazy(const LzJob &job, LzLds *lds)
     st.data_end = 0;
     st.nsyms = st.nstaged = 0;
     st.nblocks = st.blk_sym0 = st.blk_in0 = 0;
+    st.pr_hi = 0;
 
     uint32_t p = 0, cur_len = 2, cur_at = 0;
     int pending = 0; /* match_available */
+
+    /* candidate lists fetched one search ahead: slot N for position p+1, slot J for
+     * the position the parse jumps to when the pending match is emitted */
+    LANEVAR(uint32_t, nA);
+    LANEVAR(uint32_t, nB);
+    LANEVAR(uint32_t, jA);
+    LANEVAR(uint32_t, jB);
+    LANEVAR(uint32_t, cA);
+    LANEVAR(uint32_t, cB);
+    uint32_t n_at = 0xffffffffu, j_at = 0xffffffffu;
+    FOR_LANES { LV(nA) = LV(nB) = LV(jA) = LV(jB) = LV(cA) = LV(cB) = ZD_ENTRY_NONE; }
+    const uint32_t last_owner = job.n >= 3 ? job.n - 3 : 0; /* last position that has a rank */
 
     for (;;) {
         uint32_t look = st.data_end - p;
@@ -329,13 +380,68 @@ DEV void lz_parse_lazy(const LzJob &job, LzLds *lds)
                 break;
         }
         lz_ensure(job, lds, st, p);
+        lz_ensure_ranks(job, lds, st, p);
 
         const uint32_t prev_len = cur_len, prev_at = cur_at;
+        const int searching = look >= 3 && prev_len < job.cfg.lazy;
         cur_len = 2;
-        if (look >= 3 && prev_len < job.cfg.lazy) {
-            uint32_t got = lz_search(job, lds, st, p, prev_len, &cur_at);
-            if (got != 0) {
-                cur_len = got;
+
+        if (searching) {
+            /* this position's first batches: prefetched one search ago, or fetched now */
+            if (p == n_at) {
+                FOR_LANES { LV(cA) = LV(nA); LV(cB) = LV(nB); }
+            } else if (p == j_at) {
+                FOR_LANES { LV(cA) = LV(jA); LV(cB) = LV(jB); }
+            } else {
+                LZ_FETCH_FIRST(p, cA, cB);
+            }
+        }
+        /* issue the fetches for the two positions one of which is searched next:
+         * p+1, and (when a match is pending) the jump target p-1+prev_len */
+        n_at = j_at = 0xffffffffu;
+        if (job.n >= 3 && p + 1 <= last_owner) {
+            n_at = p + 1;
+            LZ_FETCH_FIRST(n_at, nA, nB);
+        }
+        if (prev_len >= 3 && job.n >= 3 && p - 1 + prev_len <= last_owner) {
+            j_at = p - 1 + prev_len;
+            LZ_FETCH_FIRST(j_at, jA, jB);
+        }
+
+        if (searching) {
+            LzSearch sc;
+            sc.p = p;
+            const uint32_t w0 = ld_u32(&lds->ring[lz_ridx(st, p)]);
+            sc.h = (((w0 & 0xff) << 10) ^ (((w0 >> 8) & 0xff) << 5) ^ ((w0 >> 16) & 0xff)) & ZD_HASH_MASK;
+            sc.s01 = w0 & 0xffff;
+            sc.sb = 0;
+            sc.look = look;
+            sc.cap = look < 258u ? look : 258u;
+            sc.nice = job.cfg.nice < look ? job.cfg.nice : look;
+            sc.best = prev_len;
+            sc.budget = prev_len >= job.cfg.good ? job.cfg.chain >> 2 : job.cfg.chain;
+            sc.where = cur_at;
+            sc.head_seen = 0;
+
+            const uint32_t tile = p >> 15;
+            const uint32_t *runA = job.sorted + (uint64_t)tile * ZD_TILE;
+            int verdict = 0;
+            /* own tile: first batch from the slot, the rest in groups of four */
+            LZ_EVAL_BATCH(cA, tile << 15, verdict);
+            if (verdict == 0)
+                LZ_WALK_RUN(runA, (int32_t)lds->prank[p & (LZ_PR - 1)] - 1, tile << 15, verdict);
+            if (verdict == 1 && tile != 0) {
+                /* older tile */
+                verdict = 0;
+                LZ_EVAL_BATCH(cB, (tile - 1) << 15, verdict);
+                if (verdict == 0)
+                    LZ_WALK_RUN(runA - ZD_TILE, (int32_t)(int16_t)lds->phib[p & (LZ_PR - 1)],
+                                (tile - 1) << 15, verdict);
+            }
+            /* verdict 3: the reference would not have called longest_match */
+            if (verdict != 3 && sc.head_seen) {
+                cur_at = sc.where;
+                cur_len = sc.best < look ? sc.best : look;
                 if (cur_len <= 5 &&
                     (job.strategy == 1 || (cur_len == 3 && p - cur_at > ZD_TOO_FAR)))
                     cur_len = 2;

@@ -75,11 +75,41 @@ __global__ __launch_bounds__(HS_WAVES * 64) void k_hash_sort(
     job.tmp = tmp + (uint64_t)tile * ZD_TILE;
     job.rank = rank + buf.rank_off;
     job.dir = (t + 1 < buf.ntiles) ? dir + (uint64_t)tile * ZD_DIR_STRIDE : nullptr;
+    job.dir_prev = nullptr;
+    job.hib = nullptr;
     const int w = (int)(threadIdx.x >> 6);
     for (int phase = 0; phase < HS_PHASES; phase++) {
         hash_sort_phase(job, &lds, w, phase);
         __syncthreads();
     }
+}
+
+/* kernel 1b: one workgroup per tile that has a predecessor in its buffer */
+__global__ __launch_bounds__(HS_WAVES * 64) void k_link_prev(
+    const uint8_t *__restrict__ in, const ZdBuf *__restrict__ bufs,
+    const uint32_t *__restrict__ tile_owner, const uint16_t *__restrict__ dir,
+    uint16_t *__restrict__ hib, uint32_t ntiles)
+{
+    const uint32_t tile = blockIdx.x;
+    if (tile >= ntiles)
+        return;
+    const ZdBuf buf = bufs[tile_owner[tile]];
+    const uint32_t t = tile - buf.tile0;
+    if (t == 0)
+        return;
+    HsTile job;
+    job.in = in + buf.in_off;
+    job.n = buf.in_len;
+    job.start = t * ZD_TILE;
+    const uint32_t owners = buf.in_len >= 3 ? buf.in_len - 2 : 0;
+    job.m = owners > job.start ? min(owners - job.start, ZD_TILE) : 0u;
+    job.sorted = nullptr;
+    job.tmp = nullptr;
+    job.rank = nullptr;
+    job.dir = nullptr;
+    job.dir_prev = dir + (uint64_t)(tile - 1) * ZD_DIR_STRIDE;
+    job.hib = hib + buf.rank_off;
+    hs_link_prev(job, (int)(threadIdx.x >> 6));
 }
 
 /* kernel 2: one wavefront per buffer, longest buffers first */
@@ -88,7 +118,7 @@ __global__ __launch_bounds__(64) void k_parse(const uint8_t *__restrict__ in,
                                               const uint32_t *__restrict__ order,
                                               const uint32_t *__restrict__ sorted,
                                               const uint16_t *__restrict__ rank,
-                                              const uint16_t *__restrict__ dir,
+                                              const uint16_t *__restrict__ hib,
                                               uint32_t *__restrict__ syms,
                                               ZdBlockRec *__restrict__ recs,
                                               ZdParseOut *__restrict__ pout,
@@ -104,7 +134,7 @@ __global__ __launch_bounds__(64) void k_parse(const uint8_t *__restrict__ in,
     job.n = buf.in_len;
     job.sorted = sorted + (uint64_t)buf.tile0 * ZD_TILE;
     job.rank = rank + buf.rank_off;
-    job.dir = dir + (uint64_t)buf.tile0 * ZD_DIR_STRIDE;
+    job.hib = hib + buf.rank_off;
     job.syms = syms + buf.sym_off;
     job.blocks = recs + buf.blk0;
     job.out = pout + b;
@@ -272,7 +302,7 @@ struct zsc_hip_deflate_plan {
     std::vector<ZdBuf> bufs; /* in_off / out_off are absolute in the caller's buffers */
     std::vector<SubBatch> subs;
     /* scratch shared by all sub-batches (sized for the largest) */
-    DevBuf d_sorted, d_tmp_syms, d_rank, d_dir, d_recs, d_plans, d_pout;
+    DevBuf d_sorted, d_tmp_syms, d_rank, d_hib, d_dir, d_recs, d_plans, d_pout;
     DevBuf d_res; /* one ZdResult per buffer of the whole plan */
     uint64_t rank_base_off = 0;
     bool profile = false;
@@ -467,7 +497,7 @@ extern "C" ZlibReturn zsc_hip_deflate_plan_create(zsc_hip_deflate_plan **plan_ou
     const uint64_t tile_words = max_tiles * ZD_TILE;
     bool ok = pl->d_sorted.ensure(tile_words * 4) &&
               pl->d_tmp_syms.ensure(std::max<uint64_t>(tile_words, max_syms) * 4) &&
-              pl->d_rank.ensure(max_rank_span * 2) &&
+              pl->d_rank.ensure(max_rank_span * 2) && pl->d_hib.ensure(max_rank_span * 2) &&
               pl->d_dir.ensure(max_tiles * ZD_DIR_STRIDE * 2) &&
               pl->d_recs.ensure(max_slots * sizeof(ZdBlockRec)) &&
               pl->d_plans.ensure(max_slots * sizeof(ZdBlockPlan)) &&
@@ -477,7 +507,7 @@ extern "C" ZlibReturn zsc_hip_deflate_plan_create(zsc_hip_deflate_plan **plan_ou
         zsc_hip_deflate_plan_destroy(pl);
         return Z_MEM_ERROR;
     }
-    pl->scratch_bytes += pl->d_sorted.bytes + pl->d_tmp_syms.bytes + pl->d_rank.bytes +
+    pl->scratch_bytes += pl->d_sorted.bytes + pl->d_tmp_syms.bytes + pl->d_rank.bytes + pl->d_hib.bytes +
                          pl->d_dir.bytes + pl->d_recs.bytes + pl->d_plans.bytes +
                          pl->d_pout.bytes + pl->d_res.bytes;
     *plan_out = pl;
@@ -524,6 +554,7 @@ extern "C" ZlibReturn zsc_hip_deflate_plan_run(zsc_hip_deflate_plan *pl, const v
         uint32_t *sorted = (uint32_t *)pl->d_sorted.p;
         uint32_t *tmp_syms = (uint32_t *)pl->d_tmp_syms.p;
         uint16_t *rank = (uint16_t *)pl->d_rank.p;
+        uint16_t *hib = (uint16_t *)pl->d_hib.p;
         uint16_t *dir = (uint16_t *)pl->d_dir.p;
         ZdBlockRec *recs = (ZdBlockRec *)pl->d_recs.p;
         ZdBlockPlan *plans = (ZdBlockPlan *)pl->d_plans.p;
@@ -535,10 +566,13 @@ extern "C" ZlibReturn zsc_hip_deflate_plan_run(zsc_hip_deflate_plan *pl, const v
         hipLaunchKernelGGL(k_hash_sort, dim3(sb.ntiles), dim3(HS_WAVES * 64), 0, st, in, bufs,
                            (const uint32_t *)sb.d_tile_owner.p, sorted, tmp_syms, rank, dir,
                            sb.ntiles);
+        hipLaunchKernelGGL(k_link_prev, dim3(sb.ntiles), dim3(HS_WAVES * 64), 0, st, in, bufs,
+                           (const uint32_t *)sb.d_tile_owner.p, (const uint16_t *)dir, hib,
+                           sb.ntiles);
         mark();
         hipLaunchKernelGGL(k_parse, dim3(sb.count), dim3(64), 0, st, in, bufs,
                            (const uint32_t *)sb.d_order.p, (const uint32_t *)sorted,
-                           (const uint16_t *)rank, (const uint16_t *)dir, tmp_syms, recs, pout,
+                           (const uint16_t *)rank, (const uint16_t *)hib, tmp_syms, recs, pout,
                            cfg, sb.count);
         mark();
         hipLaunchKernelGGL(k_huff_plan, dim3(sb.nslots), dim3(64), 0, st, bufs,
@@ -627,6 +661,7 @@ extern "C" void zsc_hip_deflate_plan_destroy(zsc_hip_deflate_plan *pl)
     pl->d_sorted.release();
     pl->d_tmp_syms.release();
     pl->d_rank.release();
+    pl->d_hib.release();
     pl->d_dir.release();
     pl->d_recs.release();
     pl->d_plans.release();
