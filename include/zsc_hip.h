@@ -98,6 +98,26 @@ uint64_t zsc_hip_deflate_plan_scratch_bytes(const zsc_hip_deflate_plan *plan);
 
 void zsc_hip_deflate_plan_destroy(zsc_hip_deflate_plan *plan);
 
+/* device-resident inflate batches ------------------------------------------ */
+
+/* Stream i occupies [src_offsets[i], +source_lens[i]) of the device input (offsets
+ * multiples of 16, 64 readable bytes after the last stream) and decodes into
+ * [dst_offsets[i], +dest_caps[i]) of the device output (offsets multiples of 16).
+ * Results per stream as zsc_uncompress2 reports them: status, bytes written,
+ * bytes consumed.  kernel_ms (may be NULL): device time of the last run from HIP
+ * events on the run's stream. */
+typedef struct zsc_hip_inflate_plan zsc_hip_inflate_plan;
+
+ZlibReturn zsc_hip_inflate_plan_create(zsc_hip_inflate_plan **plan, U32 count,
+                                       const U32 *source_lens, const uint64_t *src_offsets,
+                                       const U32 *dest_caps, const uint64_t *dst_offsets,
+                                       I32 window_bits);
+ZlibReturn zsc_hip_inflate_plan_run(zsc_hip_inflate_plan *plan, const void *d_src, void *d_dst,
+                                    void *hip_stream);
+ZlibReturn zsc_hip_inflate_plan_results(zsc_hip_inflate_plan *plan, U32 *dest_lens,
+                                        U32 *consumed, I32 *statuses, float *kernel_ms);
+void zsc_hip_inflate_plan_destroy(zsc_hip_inflate_plan *plan);
+
 #ifdef __cplusplus
 }
 #endif

@@ -19,6 +19,7 @@ struct uint4 { uint32_t x, y, z, w; };
 #include "../../zsc_amd/csrc/huff_plan.h"
 #include "../../zsc_amd/csrc/bit_emit.h"
 #include "../../zsc_amd/csrc/checksum.h"
+#include "../../zsc_amd/csrc/inflate.h"
 
 static const ZdLevel kLevels[10] = {
     {0, 0, 0, 0, 0},       {4, 4, 8, 4, 0},       {4, 5, 16, 8, 0},     {4, 6, 32, 32, 0},
@@ -185,5 +186,23 @@ extern "C" int emu_compress(const uint8_t *src, uint32_t n, int level, int wrap,
     *out_len = res.out_len;
     if (res.status == 0)
         memcpy(out, outw.data(), res.out_len);
+    return res.status;
+}
+
+extern "C" int emu_uncompress(const uint8_t *src, uint32_t n, int window_bits, uint8_t *dst, uint32_t cap,
+                              uint32_t *out_len, uint32_t *consumed)
+{
+    std::vector<uint8_t> in((size_t)n + 64, 0);
+    memcpy(in.data(), src, n);
+    std::vector<uint8_t> out((size_t)cap + 64, 0xEE);
+    InfJob job = {in.data(), n, out.data(), cap, window_bits};
+    InfLds *lds = (InfLds *)malloc(sizeof(InfLds));
+    memset(lds, 0x3C, sizeof(InfLds));
+    InfResult res;
+    inflate_stream(job, lds, &res);
+    free(lds);
+    *out_len = res.out_len;
+    *consumed = res.consumed;
+    memcpy(dst, out.data(), res.out_len <= cap ? res.out_len : cap);
     return res.status;
 }

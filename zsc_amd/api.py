@@ -63,6 +63,14 @@ def _load() -> C.CDLL:
     L.zsc_hip_compress_batch.argtypes = [C.c_uint32, C.POINTER(C.c_char_p), u32p,
                                          C.POINTER(C.c_void_p), u32p, i32p, C.c_int32, C.c_int32,
                                          C.c_int32, C.c_int32]
+    L.zsc_hip_uncompress_batch.argtypes = [C.c_uint32, C.POINTER(C.c_char_p), u32p,
+                                           C.POINTER(C.c_void_p), u32p, i32p, C.c_int32]
+    L.zsc_hip_inflate_plan_create.argtypes = [C.POINTER(C.c_void_p), C.c_uint32, u32p, u64p, u32p,
+                                              u64p, C.c_int32]
+    L.zsc_hip_inflate_plan_run.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
+    L.zsc_hip_inflate_plan_results.argtypes = [C.c_void_p, u32p, u32p, i32p, C.POINTER(C.c_float)]
+    L.zsc_hip_inflate_plan_destroy.argtypes = [C.c_void_p]
+    L.zsc_hip_inflate_plan_destroy.restype = None
     L.zsc_hip_deflate_plan_layout.argtypes = [C.c_uint32, u32p, C.c_int32, C.c_int32, C.c_int32,
                                               u64p, u64p, u32p, u64p, u64p]
     L.zsc_hip_deflate_plan_create.argtypes = [C.POINTER(C.c_void_p), C.c_uint32, u32p, u64p, u64p,
@@ -191,6 +199,69 @@ def compress_batch(sources: Sequence[bytes], level: int = 6, window_bits: int = 
                                     mem_level, strategy)
     outs = [bufs[i].raw[:dlen[i]] for i in range(count)] if rc == Z_OK else []
     return rc, outs, list(stat)
+
+
+def uncompress_batch(sources: Sequence[bytes], dest_caps: Sequence[int],
+                     window_bits: int = DEF_WBITS) -> Tuple[int, List[bytes], List[int], List[int]]:
+    """zsc_hip_uncompress_batch: every item behaves like one zsc_uncompress2 call.
+    Returns (rc, outputs, consumed, statuses)."""
+    count = len(sources)
+    srcs = (C.c_char_p * count)(*sources)
+    slen = (C.c_uint32 * count)(*[len(s) for s in sources])
+    bufs = [C.create_string_buffer(max(c, 1)) for c in dest_caps]
+    dsts = (C.c_void_p * count)(*[C.addressof(b) for b in bufs])
+    dlen = (C.c_uint32 * count)(*dest_caps)
+    stat = (C.c_int32 * count)()
+    rc = lib.zsc_hip_uncompress_batch(count, srcs, slen, dsts, dlen, stat, window_bits)
+    outs = [bufs[i].raw[:dlen[i]] for i in range(count)] if rc == Z_OK else []
+    return rc, outs, list(slen), list(stat)
+
+
+class InflatePlan:
+    """Device-resident inflate batch (see include/zsc_hip.h)."""
+
+    def __init__(self, source_lens: Sequence[int], dest_caps: Sequence[int],
+                 window_bits: int = DEF_WBITS):
+        self.count = n = len(source_lens)
+        so, do, sb, db = [], [], 0, 0
+        for sl, dc in zip(source_lens, dest_caps):
+            so.append(sb)
+            do.append(db)
+            sb += (sl + 64 + 15) & ~15
+            db += (dc + 64 + 15) & ~15
+        self.src_offsets, self.dst_offsets = so, do
+        self.src_bytes, self.dst_bytes = sb + 64, db + 64
+        self._h = C.c_void_p()
+        rc = lib.zsc_hip_inflate_plan_create(C.byref(self._h), n, (C.c_uint32 * n)(*source_lens),
+                                             (C.c_uint64 * n)(*so), (C.c_uint32 * n)(*dest_caps),
+                                             (C.c_uint64 * n)(*do), window_bits)
+        if rc != Z_OK:
+            raise RuntimeError(f"zsc_hip_inflate_plan_create failed: {rc}")
+
+    def run(self, d_src: int, d_dst: int, stream: int = 0) -> None:
+        rc = lib.zsc_hip_inflate_plan_run(self._h, C.c_void_p(d_src), C.c_void_p(d_dst),
+                                          C.c_void_p(stream))
+        if rc != Z_OK:
+            raise RuntimeError(f"zsc_hip_inflate_plan_run failed: {rc}")
+
+    def results(self):
+        n = self.count
+        lens, used, stat, ms = (C.c_uint32 * n)(), (C.c_uint32 * n)(), (C.c_int32 * n)(), C.c_float()
+        rc = lib.zsc_hip_inflate_plan_results(self._h, lens, used, stat, C.byref(ms))
+        if rc != Z_OK:
+            raise RuntimeError(f"zsc_hip_inflate_plan_results failed: {rc}")
+        return list(lens), list(used), list(stat), ms.value
+
+    def close(self) -> None:
+        if self._h:
+            lib.zsc_hip_inflate_plan_destroy(self._h)
+            self._h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
 
 
 class DeflatePlan:

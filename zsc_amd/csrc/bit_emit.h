@@ -66,6 +66,7 @@ DEV void be_flush(BeLds *lds, BeState &st, int final)
         }
     }
     const uint32_t carry = lds->stage[nfull < BE_STAGE_WORDS ? nfull : 0];
+    WAVE_SYNC();
     for (uint32_t i = 0; i <= nfull && i < BE_STAGE_WORDS; i += WAVE) {
         FOR_LANES
         {
@@ -74,7 +75,9 @@ DEV void be_flush(BeLds *lds, BeState &st, int final)
                 lds->stage[k] = 0;
         }
     }
+    WAVE_SYNC();
     ON_LANE0 { lds->stage[0] = final ? 0u : carry; }
+    WAVE_SYNC();
     st.wbase += nfull;
 }
 
@@ -100,6 +103,7 @@ DEV void be_flush(BeLds *lds, BeState &st, int final)
             }                                                                   \
         }                                                                       \
         (st).pos += _tot;                                                       \
+        WAVE_SYNC();                                                            \
         be_flush((lds), (st), 0);                                               \
     } while (0)
 
@@ -138,6 +142,7 @@ DEV void emit_block(const uint8_t *in, const uint32_t *syms, const ZdBlockRec *r
     for (int i = 0; i < BE_STAGE_WORDS; i += WAVE) {
         FOR_LANES { lds->stage[i + LANE] = 0; }
     }
+    WAVE_SYNC();
 
     if (type == ZD_BT_STORED) {
         /* reference _tr_stored_block, src/trees.c:838-849 */
@@ -207,6 +212,7 @@ DEV void emit_block(const uint8_t *in, const uint32_t *syms, const ZdBlockRec *r
         }
     }
 
+    WAVE_SYNC();
     /* 3-bit block header, then (dynamic) the tree description, 8 bits per lane */
     {
         LANEVAR(uint64_t, bits);

@@ -111,6 +111,7 @@ DEV uint32_t ck_crc32(const uint8_t *in, uint32_t n, CkLds *lds)
             lds->table[i + LANE] = c;
         }
     }
+    WAVE_SYNC();
     const uint32_t seg = (n + WAVE - 1) / WAVE;
     FOR_LANES
     {
@@ -122,6 +123,7 @@ DEV uint32_t ck_crc32(const uint8_t *in, uint32_t n, CkLds *lds)
         lds->part[LANE] = ~c;
         lds->plen[LANE] = hi > lo ? hi - lo : 0u;
     }
+    WAVE_SYNC();
     uint32_t acc = 0;
     ON_LANE0
     {
@@ -133,6 +135,7 @@ DEV uint32_t ck_crc32(const uint8_t *in, uint32_t n, CkLds *lds)
         }
         lds->part[0] = acc;
     }
+    WAVE_SYNC();
     return lds->part[0];
 }
 

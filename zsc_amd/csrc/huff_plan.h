@@ -396,6 +396,7 @@ DEV void huff_plan_block(const uint32_t *syms, const ZdBlockRec *rec, uint32_t s
             }
         }
     }
+    WAVE_SYNC();
     int last_bl = 0;
     uint32_t type = ZD_BT_DYNAMIC;
     ON_LANE0
@@ -451,6 +452,7 @@ DEV void huff_plan_block(const uint32_t *syms, const ZdBlockRec *rec, uint32_t s
                           : type == ZD_BT_STATIC ? 3u + h->static_bits : 0u;
         plan->bit_off = 0;
     }
+    WAVE_SYNC();
     /* publish the tables the bit packer needs */
     for (int i = 0; i < HP_LCODES; i += WAVE) {
         FOR_LANES

@@ -1,0 +1,653 @@
+/*
+ * inflate.h -- kernel 5: DEFLATE decoding, one wavefront per stream.
+ *
+ * Restates the reference's inflate() state machine for one-shot use
+ * (src/inflate.c:704-1404: header :740-954, block type :975-1009, stored :1010-1049,
+ * dynamic header :1050-1178, symbols :1182-1321, trailers :1322-1354), its code
+ * validation (inflate_table, src/inftrees.c:130-177) and the copy semantics of
+ * inflate_fast (src/inffast.c:125-297), as the one-shot wrapper drives them
+ * (src/zsc_uncompr.c:44-154).
+ *
+ * Decoding one stream is bit-serial, so the parallelism is across streams (config
+ * 4 has a million of them) plus, inside the wave:
+ *   - Huffman decoding without lookup tables: the next 15 bits are bit-reversed so
+ *     the code sits MSB-first, lane l tests "is the code one of the length-l codes"
+ *     (code_l - first[l] < count[l]); the lowest set bit of the ballot is the code
+ *     length.  Decoder state is ~0.8 KiB of LDS per wave (not zlib's 5.8 KiB of
+ *     tables), so 32 waves fit a CU and latency is hidden by occupancy;
+ *   - match copies are lane-parallel even when source and destination overlap:
+ *     byte i of a copy comes from pos - dist + (i mod dist), which always lies
+ *     before the copy's first byte;
+ *   - input is consumed from a 256-byte chunk held across the lanes of one VGPR
+ *     (readlane), output goes through a 1 KiB LDS staging area and leaves as
+ *     coalesced stores.
+ * Byte counts follow the reference: bytes are "consumed" once pulled into the bit
+ * buffer, which for both its fast and slow paths is ceil(bits used / 8).
+ */
+#ifndef ZSC_INFLATE_H
+#define ZSC_INFLATE_H
+
+#include "checksum.h"
+#include "wave.h"
+
+#define INF_STAGE 1024u
+
+typedef struct {
+    uint16_t count[16];
+    uint16_t first[16]; /* first canonical code of each length */
+    uint16_t offs[16];  /* index of that code's symbol in sym[] */
+    uint16_t fill[16];  /* scratch of inf_build */
+    uint16_t sym[320];
+    uint32_t max_len;
+    uint32_t empty;
+} InfCode;
+
+typedef struct {
+    InfCode lit, dist, cl;
+    uint16_t lens[320];
+    uint8_t stage[INF_STAGE + 320]; /* output not yet stored: [flushed, pos) */
+    CkLds ck;
+} InfLds;
+
+typedef struct {
+    const uint8_t *src;
+    uint32_t n;
+    uint8_t *dst;
+    uint32_t cap;
+    int32_t window_bits;
+} InfJob;
+
+typedef struct {
+    int32_t status; /* ZlibReturn of the reference's zsc_uncompress2 */
+    uint32_t out_len;
+    uint32_t consumed;
+    uint32_t pad;
+} InfResult;
+
+/* wave-uniform bit reader over a lane-distributed 256-byte chunk */
+typedef struct {
+    uint64_t hold;
+    uint32_t bits;     /* valid bits in hold */
+    uint32_t next;     /* next input byte to pull into hold */
+    uint32_t chunk_at; /* input offset of the chunk held in `cur` (multiple of 256) */
+    uint64_t used;     /* bits consumed so far */
+} InfBits;
+
+#define INF_OK 0
+#define INF_END 1
+#define INF_NEED_DICT 2
+#define INF_DATA (-3)
+#define INF_BUF (-5)
+
+/* build a canonical decoder from code lengths.  kind 0: code-length code, 1: literal/
+ * length, 2: distance.  Returns 0, or -1 for an invalid set (src/inftrees.c:168-177). */
+DEV int inf_build(InfCode *c, const uint16_t *lens, int n, int kind)
+{
+    int rc = 0;
+    ON_LANE0
+    {
+        for (int i = 0; i < 16; i++)
+            c->count[i] = 0;
+        for (int i = 0; i < n; i++)
+            c->count[lens[i]]++;
+        int max = 15;
+        while (max >= 1 && c->count[max] == 0)
+            max--;
+        c->max_len = (uint32_t)max;
+        c->empty = max == 0;
+        if (max != 0) {
+            int left = 1;
+            for (int l = 1; l <= 15; l++) {
+                left <<= 1;
+                left -= c->count[l];
+                if (left < 0) {
+                    rc = -1;
+                    break;
+                }
+            }
+            if (rc == 0 && left > 0 && (kind == 0 || max != 1))
+                rc = -1;
+            if (rc == 0) {
+                uint32_t code = 0, idx = 0;
+                for (int l = 1; l <= 15; l++) {
+                    code <<= 1;
+                    c->first[l] = (uint16_t)code;
+                    c->offs[l] = (uint16_t)idx;
+                    code += c->count[l];
+                    idx += c->count[l];
+                }
+                for (int l = 0; l < 16; l++)
+                    c->fill[l] = c->offs[l];
+                for (int i = 0; i < n; i++)
+                    if (lens[i])
+                        c->sym[c->fill[lens[i]]++] = (uint16_t)i;
+            }
+        }
+        c->count[0] = (uint16_t)(rc + 1); /* publish rc to the other lanes: 1 ok, 0 bad */
+    }
+    WAVE_SYNC();
+    return (int)c->count[0] - 1;
+}
+
+/* the whole stream; mirrors zsc_uncompress_gzip2 with gz_head == NULL */
+DEV void inflate_stream(const InfJob &job, InfLds *lds, InfResult *res)
+{
+    const uint8_t *src = job.src;
+    const uint32_t n = job.n, cap = job.cap;
+    uint8_t *dst = job.dst;
+
+    /* inflateReset2, reference src/inflate.c:341-356 */
+    int wrap, wb = job.window_bits;
+    if (wb < 0) {
+        wrap = 0;
+        wb = -wb;
+    } else {
+        wrap = (wb >> 4) + 5;
+        if (wb < 48)
+            wb &= 15;
+    }
+
+    InfBits br;
+    br.hold = 0;
+    br.bits = 0;
+    br.next = 0;
+    br.chunk_at = 0;
+    br.used = 0;
+    LANEVAR(uint32_t, cur); /* dword LANE of the current 256-byte input chunk */
+    FOR_LANES
+    {
+        uint32_t a = 4u * (uint32_t)LANE;
+        uint32_t v = 0;
+        if (a + 4 <= n)
+            v = ld_u32(src + a);
+        else
+            for (uint32_t j = 0; j < 4; j++)
+                if (a + j < n)
+                    v |= (uint32_t)src[a + j] << (8 * j);
+        LV(cur) = v;
+    }
+
+    uint32_t pos = 0, flushed = 0; /* output bytes produced / stored to dst */
+    uint32_t dmax = 32768u;
+    int gzip = 0;
+    int rc = INF_OK;
+    int exhausted = 0; /* ran out of input */
+    uint32_t fail_line = 0; /* source line of the check that rejected the stream (diagnostics) */
+
+/* top up the bit buffer to at least 32 bits (or to the end of the input) */
+#define INF_REFILL()                                                                          \
+    do {                                                                                      \
+        while (br.bits <= 32 && br.next < n) {                                                \
+            if (br.next - br.chunk_at >= 256u) {                                              \
+                br.chunk_at += 256u;                                                          \
+                FOR_LANES                                                                     \
+                {                                                                             \
+                    uint32_t _a = br.chunk_at + 4u * (uint32_t)LANE;                          \
+                    uint32_t _v = 0;                                                          \
+                    if (_a + 4 <= n)                                                          \
+                        _v = ld_u32(src + _a);                                                \
+                    else                                                                      \
+                        for (uint32_t _j = 0; _j < 4; _j++)                                   \
+                            if (_a + _j < n)                                                  \
+                                _v |= (uint32_t)src[_a + _j] << (8 * _j);                     \
+                    LV(cur) = _v;                                                             \
+                }                                                                             \
+            }                                                                                 \
+            const uint32_t _o = br.next - br.chunk_at;                                        \
+            const uint32_t _w = READLANE(cur, _o >> 2);                                       \
+            /* take the bytes of this dword from the current one on (up to 4) */              \
+            uint32_t _take = 4u - (_o & 3u);                                                  \
+            if (_take > n - br.next)                                                          \
+                _take = n - br.next;                                                          \
+            if (_take * 8u > 64u - br.bits)                                                   \
+                _take = (64u - br.bits) >> 3;                                                 \
+            if (_take == 0)                                                                   \
+                break;                                                                        \
+            uint64_t _v = (uint64_t)(_w >> (8u * (_o & 3u)));                                 \
+            if (_take < 4)                                                                    \
+                _v &= (1ull << (8u * _take)) - 1ull;                                          \
+            br.hold |= _v << br.bits;                                                         \
+            br.bits += 8u * _take;                                                            \
+            br.next += _take;                                                                 \
+        }                                                                                     \
+    } while (0)
+
+/* need nb (<= 32) bits; on failure the input is exhausted */
+#define INF_NEED(nb)                     \
+    do {                                 \
+        const uint32_t _need = (uint32_t)(nb); \
+        if (br.bits < _need) {           \
+            INF_REFILL();                \
+            if (br.bits < _need) {       \
+                exhausted = 1;           \
+                rc = INF_BUF;            \
+                goto done;               \
+            }                            \
+        }                                \
+    } while (0)
+
+#define INF_TAKE(var, nb)                                          \
+    do {                                                           \
+        const uint32_t _nb = (uint32_t)(nb);                       \
+        (var) = (uint32_t)(br.hold & ((1ull << _nb) - 1ull));      \
+        br.hold >>= _nb;                                           \
+        br.bits -= _nb;                                            \
+        br.used += _nb;                                            \
+    } while (0)
+
+#define INF_BAD              \
+    do {                     \
+        rc = INF_DATA;       \
+        fail_line = __LINE__; \
+        goto done;           \
+    } while (0)
+
+/* store the completed 256-byte pieces of the staging area */
+#define INF_FLUSH(all)                                                                         \
+    do {                                                                                       \
+        uint32_t _upto = (all) ? pos : (pos & ~255u);                                          \
+        while (flushed < _upto) {                                                              \
+            uint32_t _len = _upto - flushed < 256u ? _upto - flushed : 256u;                   \
+            FOR_LANES                                                                          \
+            {                                                                                  \
+                for (uint32_t _k = (uint32_t)LANE; _k < _len; _k += WAVE)                      \
+                    dst[flushed + _k] = lds->stage[(flushed + _k) & (INF_STAGE - 1)];          \
+            }                                                                                  \
+            flushed += _len;                                                                   \
+        }                                                                                      \
+    } while (0)
+
+/* decode one symbol of code C into `sym`: -2 when the bits are not a code of the set */
+#define INF_DECODE(C, OUTSYM)                                                                    \
+    do {                                                                                      \
+        if (br.bits < 15)                                                                     \
+            INF_REFILL();                                                                     \
+        if ((C)->empty) {                                                                     \
+            /* a table of invalid-code markers of length 1 (src/inftrees.c:150-158) */        \
+            INF_NEED(1);                                                                      \
+            (OUTSYM) = -2;                                                                       \
+            break;                                                                            \
+        }                                                                                     \
+        const uint32_t _peek = (uint32_t)br.hold & 0x7fffu;                                   \
+        uint32_t _r = 0; /* the 15 bits MSB first */                                          \
+        for (int _b = 0; _b < 15; _b++)                                                       \
+            _r |= ((_peek >> _b) & 1u) << (14 - _b);                                          \
+        LANEVAR(int, _hit);                                                                   \
+        FOR_LANES                                                                             \
+        {                                                                                     \
+            int _l = LANE;                                                                    \
+            int _ok = 0;                                                                      \
+            if (_l >= 1 && _l <= (int)(C)->max_len) {                                         \
+                uint32_t _c = _r >> (15 - _l);                                                \
+                _ok = (uint32_t)(_c - (C)->first[_l]) < (uint32_t)(C)->count[_l];             \
+            }                                                                                 \
+            LV(_hit) = _ok;                                                                   \
+        }                                                                                     \
+        const uint64_t _m = BALLOT(_hit);                                                     \
+        if (_m == 0) {                                                                        \
+            /* no code matches: only possible for the lone 1-bit code (incomplete set) */     \
+            INF_NEED((C)->max_len);                                                           \
+            uint32_t _d;                                                                      \
+            INF_TAKE(_d, (C)->max_len);                                                       \
+            (void)_d;                                                                         \
+            (OUTSYM) = -2;                                                                       \
+            break;                                                                            \
+        }                                                                                     \
+        const uint32_t _len = (uint32_t)CTZ64(_m);                                            \
+        if (br.bits < _len) {                                                                 \
+            exhausted = 1;                                                                    \
+            rc = INF_BUF;                                                                     \
+            goto done;                                                                        \
+        }                                                                                     \
+        const uint32_t _code = _r >> (15 - _len);                                             \
+        (OUTSYM) = (int)(C)->sym[(C)->offs[_len] + (_code - (C)->first[_len])];                  \
+        br.hold >>= _len;                                                                     \
+        br.bits -= _len;                                                                      \
+        br.used += _len;                                                                      \
+    } while (0)
+
+    /* HEAD .. HCRC, reference src/inflate.c:740-954 */
+    if (wb && (wb < 8 || wb > 15)) {
+        rc = -2;
+        goto done;
+    }
+    if (wrap) {
+        INF_NEED(16);
+        const uint32_t hw = (uint32_t)br.hold & 0xffffu;
+        if ((wrap & 2) && hw == 0x8b1fu) {
+            uint32_t t, flags;
+            gzip = 1;
+            INF_TAKE(t, 16);
+            INF_NEED(16);
+            INF_TAKE(flags, 16);
+            if ((flags & 0xff) != 8 || (flags & 0xe000))
+                INF_BAD;
+            INF_NEED(32);
+            INF_TAKE(t, 32);
+            INF_NEED(16);
+            INF_TAKE(t, 16);
+            if (flags & 0x0400) {
+                uint32_t xlen;
+                INF_NEED(16);
+                INF_TAKE(xlen, 16);
+                for (uint32_t k = 0; k < xlen; k++) {
+                    INF_NEED(8);
+                    INF_TAKE(t, 8);
+                }
+            }
+            if (flags & 0x0800) {
+                do {
+                    INF_NEED(8);
+                    INF_TAKE(t, 8);
+                } while (t != 0);
+            }
+            if (flags & 0x1000) {
+                do {
+                    INF_NEED(8);
+                    INF_TAKE(t, 8);
+                } while (t != 0);
+            }
+            if (flags & 0x0200) {
+                const uint32_t upto = (uint32_t)(br.used >> 3);
+                uint32_t got;
+                INF_NEED(16);
+                INF_TAKE(got, 16);
+                if ((wrap & 4) && got != (ck_crc32(src, upto, &lds->ck) & 0xffffu))
+                    INF_BAD;
+            }
+        } else {
+            uint32_t t = 0;
+            (void)t;
+            if (!(wrap & 1) || ((((hw & 0xff) << 8) + (hw >> 8)) % 31u))
+                INF_BAD;
+            if ((hw & 0xf) != 8)
+                INF_BAD;
+            const uint32_t len = ((hw >> 4) & 0xf) + 8;
+            const uint32_t wbits_eff = wb ? (uint32_t)wb : len;
+            if (len > 15 || len > wbits_eff)
+                INF_BAD;
+            dmax = 1u << len;
+            INF_TAKE(t, 16);
+            if (hw & 0x2000) {
+                /* preset dictionary: the reference returns Z_NEED_DICT from the DICT state
+                 * without its exit bookkeeping, so nothing counts as consumed */
+                INF_NEED(32);
+                rc = INF_NEED_DICT;
+                br.used = 0;
+                goto done;
+            }
+        }
+    }
+
+    /* blocks */
+    for (;;) {
+        uint32_t last, type;
+        INF_NEED(3);
+        INF_TAKE(last, 1);
+        INF_TAKE(type, 2);
+        if (type == 3)
+            INF_BAD;
+        if (type == 0) {
+            uint32_t t, v;
+            INF_TAKE(t, br.bits & 7u);
+            (void)t;
+            INF_NEED(32);
+            INF_TAKE(v, 32);
+            if ((v & 0xffff) != ((v >> 16) ^ 0xffff))
+                INF_BAD;
+            uint32_t len = v & 0xffff;
+            /* the remaining bytes of the bit buffer belong to the stored data */
+            const uint32_t at = (uint32_t)(br.used >> 3); /* input offset of the first data byte */
+            uint32_t can = len;
+            int short_in = 0, short_out = 0;
+            if (can > n - at) {
+                can = n - at;
+                short_in = 1;
+            }
+            if (can > cap - pos) {
+                can = cap - pos;
+                short_out = 1;
+            }
+            /* copy through the staging area, 256 bytes per step */
+            for (uint32_t k = 0; k < can; k += 256u) {
+                const uint32_t step = can - k < 256u ? can - k : 256u;
+                FOR_LANES
+                {
+                    for (uint32_t j = (uint32_t)LANE; j < step; j += WAVE)
+                        lds->stage[(pos + j) & (INF_STAGE - 1)] = src[at + k + j];
+                }
+                WAVE_SYNC();
+                pos += step;
+                INF_FLUSH(0);
+            }
+            br.used = ((uint64_t)at + can) * 8u;
+            br.hold = 0;
+            br.bits = 0;
+            br.next = at + can;
+            if (br.next - br.chunk_at >= 256u || br.next < br.chunk_at) {
+                /* re-seat the input chunk at the new position */
+                br.chunk_at = br.next & ~255u;
+                FOR_LANES
+                {
+                    uint32_t a = br.chunk_at + 4u * (uint32_t)LANE;
+                    uint32_t w = 0;
+                    if (a + 4 <= n)
+                        w = ld_u32(src + a);
+                    else
+                        for (uint32_t j = 0; j < 4; j++)
+                            if (a + j < n)
+                                w |= (uint32_t)src[a + j] << (8 * j);
+                    LV(cur) = w;
+                }
+            }
+            if (short_in || short_out) {
+                rc = INF_BUF; /* COPY state leaves with nothing more to do, src/inflate.c:1037-1039 */
+                goto done;
+            }
+        } else {
+            if (type == 1) {
+                FOR_LANES
+                {
+                    for (int s = LANE; s < 288; s += WAVE)
+                        lds->lens[s] = (uint16_t)(s < 144 ? 8 : s < 256 ? 9 : s < 280 ? 7 : 8);
+                }
+                WAVE_SYNC();
+                (void)inf_build(&lds->lit, lds->lens, 288, 1);
+                FOR_LANES
+                {
+                    if (LANE < 32)
+                        lds->lens[LANE] = 5;
+                }
+                WAVE_SYNC();
+                (void)inf_build(&lds->dist, lds->lens, 32, 2);
+            } else {
+                uint32_t nlen, ndist, ncode;
+                INF_NEED(14);
+                INF_TAKE(nlen, 5);
+                INF_TAKE(ndist, 5);
+                INF_TAKE(ncode, 4);
+                nlen += 257;
+                ndist += 1;
+                ncode += 4;
+                if (nlen > 286 || ndist > 30)
+                    INF_BAD;
+                FOR_LANES
+                {
+                    if (LANE < 19)
+                        lds->lens[LANE] = 0;
+                }
+                WAVE_SYNC();
+                for (uint32_t i = 0; i < ncode; i++) {
+                    uint32_t v;
+                    INF_NEED(3);
+                    INF_TAKE(v, 3);
+                    const uint8_t order[19] = {16, 17, 18, 0, 8, 7, 9, 6, 10, 5, 11, 4, 12, 3, 13, 2, 14, 1, 15};
+                    ON_LANE0 { lds->lens[order[i]] = (uint16_t)v; }
+                    WAVE_SYNC();
+                }
+                if (inf_build(&lds->cl, lds->lens, 19, 0))
+                    INF_BAD;
+                uint32_t have = 0;
+                while (have < nlen + ndist) {
+                    int sym;
+                    INF_DECODE(&lds->cl, sym);
+                    if (sym < 0)
+                        INF_BAD;
+                    if (sym < 16) {
+                        ON_LANE0 { lds->lens[have] = (uint16_t)sym; }
+                        WAVE_SYNC();
+                        have++;
+                        continue;
+                    }
+                    uint32_t rep, val = 0;
+                    if (sym == 16) {
+                        INF_NEED(2);
+                        if (have == 0)
+                            INF_BAD;
+                        val = lds->lens[have - 1];
+                        INF_TAKE(rep, 2);
+                        rep += 3;
+                    } else if (sym == 17) {
+                        INF_NEED(3);
+                        INF_TAKE(rep, 3);
+                        rep += 3;
+                    } else {
+                        INF_NEED(7);
+                        INF_TAKE(rep, 7);
+                        rep += 11;
+                    }
+                    if (have + rep > nlen + ndist)
+                        INF_BAD;
+                    FOR_LANES
+                    {
+                        for (uint32_t k = (uint32_t)LANE; k < rep; k += WAVE)
+                            lds->lens[have + k] = (uint16_t)val;
+                    }
+                    WAVE_SYNC();
+                    have += rep;
+                }
+                if (lds->lens[256] == 0)
+                    INF_BAD;
+                if (inf_build(&lds->lit, lds->lens, (int)nlen, 1))
+                    INF_BAD;
+                if (inf_build(&lds->dist, lds->lens + nlen, (int)ndist, 2))
+                    INF_BAD;
+            }
+            /* symbols */
+            for (;;) {
+                int sym;
+                INF_DECODE(&lds->lit, sym);
+                if (sym == -2)
+                    INF_BAD;
+                if (sym < 256) {
+                    if (pos >= cap) {
+                        rc = INF_BUF;
+                        goto done;
+                    }
+                    ON_LANE0 { lds->stage[pos & (INF_STAGE - 1)] = (uint8_t)sym; }
+                    WAVE_SYNC();
+                    pos++;
+                    if ((pos & 255u) == 0)
+                        INF_FLUSH(0);
+                    continue;
+                }
+                if (sym == 256)
+                    break;
+                if (sym > 285)
+                    INF_BAD;
+                uint32_t c = (uint32_t)sym - 257u, xb, ex, len;
+                xb = (c < 8 || c == 28) ? 0u : (c - 4u) >> 2;
+                INF_NEED(xb);
+                INF_TAKE(ex, xb);
+                len = c < 8 ? c + 3u : c == 28 ? 258u : ((4u + ((c - 4u) & 3u)) << ((c - 4u) >> 2)) + 3u + ex;
+                int ds;
+                INF_DECODE(&lds->dist, ds);
+                if (ds < 0 || ds > 29)
+                    INF_BAD;
+                xb = ds < 4 ? 0u : ((uint32_t)ds >> 1) - 1u;
+                INF_NEED(xb);
+                INF_TAKE(ex, xb);
+                const uint32_t dist = (ds < 4 ? (uint32_t)ds : (2u + ((uint32_t)ds & 1u)) << (((uint32_t)ds >> 1) - 1u)) + 1u + ex;
+                if (dist > dmax || dist > pos)
+                    INF_BAD;
+                uint32_t can = len;
+                if (can > cap - pos)
+                    can = cap - pos;
+                /* lane-parallel copy: byte i comes from pos - dist + (i mod dist) */
+                for (uint32_t k = 0; k < can; k += WAVE) {
+                    FOR_LANES
+                    {
+                        uint32_t i = k + (uint32_t)LANE;
+                        if (i < can) {
+                            uint32_t s = pos - dist + (i % dist);
+                            uint8_t b = s >= flushed ? lds->stage[s & (INF_STAGE - 1)] : dst[s];
+                            lds->stage[(pos + i) & (INF_STAGE - 1)] = b;
+                        }
+                    }
+                    WAVE_SYNC();
+                }
+                {
+                    const uint32_t before = pos;
+                    pos += can;
+                    if ((before >> 8) != (pos >> 8))
+                        INF_FLUSH(0);
+                }
+                if (can < len) {
+                    rc = INF_BUF;
+                    goto done;
+                }
+            }
+        }
+        if (last)
+            break;
+    }
+
+    /* CHECK / LENGTH, reference src/inflate.c:1322-1354 */
+    {
+        uint32_t t;
+        INF_TAKE(t, br.bits & 7u);
+        INF_FLUSH(1);
+        if (wrap) {
+            uint32_t v;
+            INF_NEED(32);
+            INF_TAKE(v, 32);
+            if (wrap & 4) {
+#ifndef ZSC_WAVE_EMU
+                __threadfence_block();
+#endif
+                const uint32_t want = gzip ? ck_crc32(dst, pos, &lds->ck) : ck_adler32(dst, pos);
+                const uint32_t got = gzip ? v : ((v >> 24) | ((v >> 8) & 0xff00u) | ((v & 0xff00u) << 8) | (v << 24));
+                if (got != want)
+                    INF_BAD;
+            }
+            if (gzip) {
+                INF_NEED(32);
+                INF_TAKE(v, 32);
+                if (v != pos)
+                    INF_BAD;
+            }
+        }
+        rc = INF_END;
+    }
+
+done:
+    INF_FLUSH(1);
+    ON_LANE0
+    {
+        uint32_t used_bytes = (uint32_t)((br.used + 7u) >> 3);
+        if (exhausted || used_bytes > n)
+            used_bytes = n;
+        res->status = rc == INF_END ? 0 : rc;
+        res->out_len = rc == INF_NEED_DICT ? 0u : pos;
+        res->consumed = rc == INF_NEED_DICT ? 0u : used_bytes;
+        res->pad = fail_line;
+    }
+#undef INF_REFILL
+#undef INF_NEED
+#undef INF_TAKE
+#undef INF_BAD
+#undef INF_FLUSH
+#undef INF_DECODE
+}
+
+#endif

@@ -88,6 +88,7 @@ DEV void lz_load_chunk(const LzJob &job, LzLds *lds, LzState &st)
             }
         }
     }
+    WAVE_SYNC();
     if (r0 == 0) {
         FOR_LANES
         {
@@ -95,6 +96,7 @@ DEV void lz_load_chunk(const LzJob &job, LzLds *lds, LzState &st)
                 lds->ring[ZD_RING + LANE] = lds->ring[LANE];
         }
     }
+    WAVE_SYNC();
     st.hi = a0 + ZD_CHUNK;
     if (st.hi - st.lo > ZD_RING)
         st.lo = st.hi - ZD_RING;
@@ -124,6 +126,7 @@ DEV void lz_flush_stage(const LzJob &job, LzLds *lds, LzState &st)
 DEV int lz_put(const LzJob &job, LzLds *lds, LzState &st, uint32_t sym)
 {
     ON_LANE0 { lds->stage[st.nstaged] = sym; }
+    WAVE_SYNC();
     st.nstaged++;
     st.nsyms++;
     if (st.nstaged == WAVE)
@@ -197,6 +200,7 @@ DEV void lz_ensure_ranks(const LzJob &job, LzLds *lds, LzState &st, uint32_t p)
             lds->prank[x & (LZ_PR - 1)] = job.rank[x];
             lds->phib[x & (LZ_PR - 1)] = job.hib[x];
         }
+        WAVE_SYNC();
         st.pr_hi += WAVE;
     }
 }

@@ -40,6 +40,7 @@
 #define FOR_LANES for (int _lane = 0; _lane < WAVE; ++_lane)
 #define LANE (_lane)
 #define ON_LANE0
+#define WAVE_SYNC() ((void)0)
 #define WG_BARRIER() ((void)0)
 
 template <typename T>
@@ -110,6 +111,17 @@ static inline uint32_t ld_u16(const uint8_t *p)
 #define FOR_LANES
 #define LANE ((int)(threadIdx.x & 63))
 #define ON_LANE0 if ((threadIdx.x & 63) == 0)
+/* Lanes of one wave exchange data through LDS without a hardware barrier (LDS
+ * operations of a wave execute in order), but the COMPILER reasons per thread: a
+ * load may legally be hoisted above a store that only another lane executes.
+ * WAVE_SYNC() is the ordering point: a wavefront-scope release/acquire fence pair
+ * around a wave barrier -- no instructions, only a scheduling/memory barrier. */
+#define WAVE_SYNC()                                              \
+    do {                                                         \
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");   \
+        __builtin_amdgcn_wave_barrier();                         \
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");   \
+    } while (0)
 #define WG_BARRIER() __syncthreads()
 
 #define BALLOT(name) __ballot(name)

@@ -23,6 +23,7 @@
 #include "checksum.h"
 #include "hash_sort.h"
 #include "huff_plan.h"
+#include "inflate.h"
 #include "lz_parse.h"
 #include "zsc_dev.h"
 
@@ -199,6 +200,34 @@ __global__ __launch_bounds__(64) void k_emit(const uint8_t *__restrict__ in,
     const ZdBlockRec *rec = &recs[slot];
     emit_block(in + buf.in_off, syms + buf.sym_off + rec->sym_begin, rec, &plans[slot],
                (uint32_t *)(out + buf.out_off), &lds);
+}
+
+/* one stream of an inflate batch */
+typedef struct {
+    uint64_t src_off, dst_off;
+    uint32_t src_len, dst_cap;
+} ZdInfItem;
+
+/* kernel 5: one wavefront per compressed stream */
+__global__ __launch_bounds__(64) void k_inflate(const uint8_t *__restrict__ src,
+                                                uint8_t *__restrict__ dst,
+                                                const ZdInfItem *__restrict__ items,
+                                                const uint32_t *__restrict__ order,
+                                                InfResult *__restrict__ res, int32_t window_bits,
+                                                uint32_t count)
+{
+    __shared__ InfLds lds;
+    if (blockIdx.x >= count)
+        return;
+    const uint32_t i = order[blockIdx.x];
+    const ZdInfItem it = items[i];
+    InfJob job;
+    job.src = src + it.src_off;
+    job.n = it.src_len;
+    job.dst = dst + it.dst_off;
+    job.cap = it.dst_cap;
+    job.window_bits = window_bits;
+    inflate_stream(job, &lds, &res[i]);
 }
 
 /* ------------------------------------------------------------------------ */
@@ -744,17 +773,179 @@ extern "C" ZlibReturn zsc_hip_compress_batch(U32 count, const U8 *const *sources
     return rc;
 }
 
+struct zsc_hip_inflate_plan {
+    uint32_t count = 0;
+    int32_t window_bits = 15;
+    DevBuf d_items, d_order, d_res;
+    hipStream_t last_stream = nullptr;
+    hipEvent_t ev0 = nullptr, ev1 = nullptr;
+    bool timed = false;
+};
+
+extern "C" ZlibReturn zsc_hip_inflate_plan_create(zsc_hip_inflate_plan **plan_out, U32 count,
+                                                  const U32 *source_lens,
+                                                  const uint64_t *src_offsets,
+                                                  const U32 *dest_caps,
+                                                  const uint64_t *dst_offsets, I32 window_bits)
+{
+    ZSC_ASSERT(plan_out != Z_NULL);
+    *plan_out = nullptr;
+    if (zsc_hip_init(-1) != Z_OK)
+        return Z_STREAM_ERROR;
+    auto *pl = new zsc_hip_inflate_plan();
+    pl->count = count;
+    pl->window_bits = window_bits;
+    std::vector<ZdInfItem> items(count);
+    std::vector<uint32_t> order(count);
+    for (U32 i = 0; i < count; i++) {
+        items[i].src_off = src_offsets[i];
+        items[i].dst_off = dst_offsets[i];
+        items[i].src_len = source_lens[i];
+        items[i].dst_cap = dest_caps[i];
+        order[i] = i;
+    }
+    std::stable_sort(order.begin(), order.end(),
+                     [&](uint32_t a, uint32_t b) { return items[a].dst_cap > items[b].dst_cap; });
+    bool ok = pl->d_items.ensure(sizeof(ZdInfItem) * std::max(1u, count)) &&
+              pl->d_order.ensure(4ull * std::max(1u, count)) &&
+              pl->d_res.ensure(sizeof(InfResult) * std::max(1u, count));
+    if (ok && count) {
+        ok = hipMemcpy(pl->d_items.p, items.data(), sizeof(ZdInfItem) * count,
+                       hipMemcpyHostToDevice) == hipSuccess &&
+             hipMemcpy(pl->d_order.p, order.data(), 4ull * count, hipMemcpyHostToDevice) ==
+                 hipSuccess;
+    }
+    if (!ok) {
+        pl->d_items.release();
+        pl->d_order.release();
+        pl->d_res.release();
+        delete pl;
+        return Z_MEM_ERROR;
+    }
+    (void)hipEventCreate(&pl->ev0);
+    (void)hipEventCreate(&pl->ev1);
+    *plan_out = pl;
+    return Z_OK;
+}
+
+extern "C" ZlibReturn zsc_hip_inflate_plan_run(zsc_hip_inflate_plan *pl, const void *d_src,
+                                               void *d_dst, void *hip_stream)
+{
+    ZSC_ASSERT(pl != Z_NULL);
+    hipStream_t st = (hipStream_t)hip_stream;
+    pl->last_stream = st;
+    if (pl->count == 0)
+        return Z_OK;
+    (void)hipEventRecord(pl->ev0, st);
+    hipLaunchKernelGGL(k_inflate, dim3(pl->count), dim3(64), 0, st, (const uint8_t *)d_src,
+                       (uint8_t *)d_dst, (const ZdInfItem *)pl->d_items.p,
+                       (const uint32_t *)pl->d_order.p, (InfResult *)pl->d_res.p, pl->window_bits,
+                       pl->count);
+    (void)hipEventRecord(pl->ev1, st);
+    pl->timed = true;
+    HIP_TRY(hipGetLastError(), return Z_STREAM_ERROR);
+    return Z_OK;
+}
+
+extern "C" ZlibReturn zsc_hip_inflate_plan_results(zsc_hip_inflate_plan *pl, U32 *dest_lens,
+                                                   U32 *consumed, I32 *statuses, float *kernel_ms)
+{
+    ZSC_ASSERT(pl != Z_NULL);
+    HIP_TRY(hipStreamSynchronize(pl->last_stream), return Z_STREAM_ERROR);
+    std::vector<InfResult> res(pl->count);
+    if (pl->count)
+        HIP_TRY(hipMemcpy(res.data(), pl->d_res.p, sizeof(InfResult) * pl->count,
+                          hipMemcpyDeviceToHost),
+                return Z_STREAM_ERROR);
+    for (uint32_t i = 0; i < pl->count; i++) {
+        if (dest_lens)
+            dest_lens[i] = res[i].out_len;
+        if (consumed)
+            consumed[i] = res[i].consumed;
+        if (statuses)
+            statuses[i] = res[i].status;
+        if (res[i].status == Z_DATA_ERROR && getenv("ZSC_HIP_DEBUG"))
+            fprintf(stderr, "zsc_hip: stream %u rejected at inflate.h:%u\n", i, res[i].pad);
+    }
+    if (kernel_ms) {
+        *kernel_ms = 0.f;
+        if (pl->timed)
+            (void)hipEventElapsedTime(kernel_ms, pl->ev0, pl->ev1);
+    }
+    return Z_OK;
+}
+
+extern "C" void zsc_hip_inflate_plan_destroy(zsc_hip_inflate_plan *pl)
+{
+    if (!pl)
+        return;
+    pl->d_items.release();
+    pl->d_order.release();
+    pl->d_res.release();
+    if (pl->ev0)
+        (void)hipEventDestroy(pl->ev0);
+    if (pl->ev1)
+        (void)hipEventDestroy(pl->ev1);
+    delete pl;
+}
+
+/* host-pointer batch: stage through one pair of device buffers */
 extern "C" ZlibReturn zsc_hip_uncompress_batch(U32 count, const U8 *const *sources,
                                                U32 *source_lens, U8 *const *dests,
                                                U32 *dest_lens, I32 *statuses, I32 window_bits)
 {
-    (void)count;
-    (void)sources;
-    (void)source_lens;
-    (void)dests;
-    (void)dest_lens;
-    (void)statuses;
-    (void)window_bits;
-    ZSC_WARN("zsc_hip: the inflate kernels are not built yet (DESIGN.md, next).");
-    return Z_STREAM_ERROR;
+    ZSC_ASSERT(sources != Z_NULL);
+    ZSC_ASSERT(source_lens != Z_NULL);
+    ZSC_ASSERT(dests != Z_NULL);
+    ZSC_ASSERT(dest_lens != Z_NULL);
+    if (count == 0)
+        return Z_OK;
+    if (zsc_hip_init(-1) != Z_OK)
+        return Z_STREAM_ERROR;
+    std::vector<uint64_t> so(count), dof(count);
+    uint64_t sb = 0, db = 0;
+    for (U32 i = 0; i < count; i++) {
+        so[i] = sb;
+        dof[i] = db;
+        sb += ((uint64_t)source_lens[i] + 64u + 15u) & ~15ull;
+        db += ((uint64_t)dest_lens[i] + 64u + 15u) & ~15ull;
+    }
+    zsc_hip_inflate_plan *pl = nullptr;
+    ZlibReturn rc = zsc_hip_inflate_plan_create(&pl, count, source_lens, so.data(), dest_lens,
+                                                dof.data(), window_bits);
+    if (rc != Z_OK)
+        return rc;
+    DevBuf d_src, d_dst;
+    if (!d_src.ensure(sb + 64) || !d_dst.ensure(db + 64)) {
+        d_src.release();
+        d_dst.release();
+        zsc_hip_inflate_plan_destroy(pl);
+        return Z_MEM_ERROR;
+    }
+    for (U32 i = 0; i < count && rc == Z_OK; i++) {
+        ZSC_ASSERT(sources[i] != Z_NULL);
+        if (source_lens[i] && hipMemcpy((uint8_t *)d_src.p + so[i], sources[i], source_lens[i],
+                                        hipMemcpyHostToDevice) != hipSuccess)
+            rc = Z_STREAM_ERROR;
+    }
+    std::vector<U32> outl(count), used(count);
+    std::vector<I32> stat(count);
+    if (rc == Z_OK)
+        rc = zsc_hip_inflate_plan_run(pl, d_src.p, d_dst.p, nullptr);
+    if (rc == Z_OK)
+        rc = zsc_hip_inflate_plan_results(pl, outl.data(), used.data(), stat.data(), nullptr);
+    for (U32 i = 0; i < count && rc == Z_OK; i++) {
+        ZSC_ASSERT(dests[i] != Z_NULL);
+        if (outl[i] && hipMemcpy(dests[i], (uint8_t *)d_dst.p + dof[i], outl[i],
+                                 hipMemcpyDeviceToHost) != hipSuccess)
+            rc = Z_STREAM_ERROR;
+        dest_lens[i] = outl[i];
+        source_lens[i] = used[i];
+        if (statuses)
+            statuses[i] = stat[i];
+    }
+    d_src.release();
+    d_dst.release();
+    zsc_hip_inflate_plan_destroy(pl);
+    return rc;
 }
