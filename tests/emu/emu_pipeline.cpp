@@ -76,6 +76,21 @@ static void build_chains(EmuChains &c, const uint8_t *src, uint32_t n)
     }
 }
 
+static void run_parse(const LzJob &job)
+{
+    if (job.cfg.slow) {
+        LzLds *lds = (LzLds *)malloc(sizeof(LzLds));
+        memset(lds, 0xA5, sizeof(LzLds));
+        lz_parse_lazy(job, lds);
+        free(lds);
+    } else {
+        LzLdsFast *lds = (LzLdsFast *)malloc(sizeof(LzLdsFast));
+        memset(lds, 0xA5, sizeof(LzLdsFast));
+        lz_parse_greedy(job, lds);
+        free(lds);
+    }
+}
+
 extern "C" int emu_sort(const uint8_t *src, uint32_t n, uint32_t *sorted_out, uint16_t *rank_out,
                         uint16_t *dir_out)
 {
@@ -90,7 +105,7 @@ extern "C" int emu_sort(const uint8_t *src, uint32_t n, uint32_t *sorted_out, ui
 extern "C" int emu_parse(const uint8_t *src, uint32_t n, int level, int strategy, uint32_t *syms,
                          uint32_t *nsyms, ZdBlockRec *blocks, uint32_t *nblocks)
 {
-    if (level < 4 || level > 9)
+    if (level < 1 || level > 9)
         return -2;
     EmuChains c;
     build_chains(c, src, n);
@@ -106,10 +121,7 @@ extern "C" int emu_parse(const uint8_t *src, uint32_t n, int level, int strategy
     job.out = &out;
     job.cfg = kLevels[level];
     job.strategy = (uint32_t)strategy;
-    LzLds *lds = (LzLds *)malloc(sizeof(LzLds));
-    memset(lds, 0xA5, sizeof(LzLds));
-    lz_parse_lazy(job, lds);
-    free(lds);
+    run_parse(job);
     *nsyms = out.nsyms;
     *nblocks = out.nblocks;
     return 0;
@@ -134,7 +146,7 @@ extern "C" uint32_t emu_crc32(const uint8_t *src, uint32_t n)
 extern "C" int emu_compress(const uint8_t *src, uint32_t n, int level, int wrap, int strategy,
                             uint8_t *out, uint32_t out_cap, uint32_t *out_len)
 {
-    if (level < 4 || level > 9)
+    if (level < 1 || level > 9)
         return -2;
     EmuChains c;
     build_chains(c, src, n);
@@ -154,10 +166,7 @@ extern "C" int emu_compress(const uint8_t *src, uint32_t n, int level, int wrap,
     job.out = &po;
     job.cfg = kLevels[level];
     job.strategy = (uint32_t)strategy;
-    LzLds *lds = (LzLds *)malloc(sizeof(LzLds));
-    memset(lds, 0xA5, sizeof(LzLds));
-    lz_parse_lazy(job, lds);
-    free(lds);
+    run_parse(job);
 
     ZdBuf buf;
     memset(&buf, 0, sizeof buf);

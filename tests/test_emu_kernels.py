@@ -49,7 +49,7 @@ def test_parse_kernel_symbols_and_blocks(emu, oracle):
     for n in SIZES + [131072]:
         for kind in ("text", "bitmap", "table", "runs", "zero"):
             data = corpus.make_buffer(kind, n, n + 11)
-            for level in (6, 9) if n <= 70000 else (6,):
+            for level in (1, 3, 6, 9) if n <= 70000 else (6, 1):
                 syms = (C.c_uint32 * (n + 64))()
                 blocks = (Rec * (n // 16383 + 4))()
                 ns, nb = C.c_uint32(), C.c_uint32()
@@ -69,8 +69,9 @@ def test_full_pipeline_streams(emu, oracle):
         for kind in ("text", "token", "bitmap", "table", "object", "random", "zero", "runs"):
             data = corpus.make_buffer(kind, n, n + 13)
             for level, wrap, wb, strat in ((6, 1, 15, 0), (9, 1, 15, 0), (4, 0, -15, 0), (6, 2, 31, 0),
-                                           (6, 1, 15, 4), (6, 1, 15, 1)):
-                if n > 40000 and (level, wrap, strat) != (6, 1, 0):
+                                           (6, 1, 15, 4), (6, 1, 15, 1), (1, 1, 15, 0), (2, 2, 31, 0),
+                                           (3, 0, -15, 0)):
+                if n > 40000 and (level, wrap, strat) not in ((6, 1, 0), (1, 1, 0)):
                     continue
                 rc, got = emu_compress(emu, data, level, wrap, strat)
                 orc, want, _ = oracle.compress(data, level, window_bits=wb, strategy=strat)

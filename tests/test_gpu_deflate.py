@@ -32,9 +32,9 @@ def test_hello_vector(z):
     assert rc == 0 and out.hex() == "789ccb48cdc9c957c800910019910449"
 
 
-def test_golden_vectors_levels_4_to_9(z):
+def test_golden_vectors_all_levels(z):
     """Streams pinned by the compiled reference (tests/golden/make_golden.py), in one batch per level."""
-    for level in (6, 9):
+    for level in (1, 6, 9):
         for wb in (15, -15, 31):
             cases = [c for c in G_DEF["deflate"] if c["level"] == level and c["window_bits"] == wb]
             if not cases:
@@ -51,11 +51,11 @@ def test_against_oracle_edge_sizes(z, oracle):
     sizes = [0, 1, 2, 3, 4, 5, 9, 257, 258, 259, 260, 261, 262, 263, 4095, 4096, 4097, 16383, 16384,
              32505, 32506, 32507, 32767, 32768, 32769, 36863, 36864, 36865, 65273, 65274, 65275,
              65276, 65535, 65536, 65537, 65798, 98304, 131072, 200001]
-    for level in (4, 5, 6, 7, 8, 9):
+    for level in (1, 2, 3, 4, 5, 6, 7, 8, 9):
         bufs = []
         for n in sizes:
             for kind in ("text", "bitmap", "runs", "zero", "random"):
-                if level not in (6, 9) and kind not in ("text", "runs"):
+                if level not in (1, 6, 9) and kind not in ("text", "runs"):
                     continue
                 bufs.append(corpus.make_buffer(kind, n, n * 5 + level))
         rc, outs, stats = z.compress_batch(bufs, level=level)

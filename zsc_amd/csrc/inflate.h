@@ -606,6 +606,7 @@ DEV void inflate_stream(const InfJob &job, InfLds *lds, InfResult *res)
     {
         uint32_t t;
         INF_TAKE(t, br.bits & 7u);
+        (void)t;
         INF_FLUSH(1);
         if (wrap) {
             uint32_t v;

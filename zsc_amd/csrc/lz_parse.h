@@ -31,12 +31,27 @@
 
 #define LZ_PR 512u /* positions covered by the rank/hib look-ahead ring */
 
-typedef struct {
-    uint8_t ring[ZD_RING + 512]; /* sliding window; first 16 bytes mirrored after the end, rest slack for masked over-reads */
-    uint32_t stage[WAVE];       /* symbols waiting for a coalesced store */
-    uint16_t prank[LZ_PR];      /* rank[] of the next few hundred positions */
-    uint16_t phib[LZ_PR];       /* hib[] of the same positions */
-} LzLds;
+/* LDS of the lazy parser (levels 4-9): 36 KiB window ring + look-ahead rings = 39 680 B,
+ * four waves per CU */
+struct LzLds {
+    static constexpr uint32_t RING = ZD_RING, CHUNK = ZD_CHUNK;
+    static constexpr bool HAS_INS = false;
+    uint8_t ring[RING + 512]; /* sliding window; first 16 bytes mirrored after the end, rest slack for masked over-reads */
+    uint32_t stage[WAVE];     /* symbols waiting for a coalesced store */
+    uint16_t prank[LZ_PR];    /* rank[] of the next few hundred positions */
+    uint16_t phib[LZ_PR];     /* hib[] of the same positions */
+};
+
+/* LDS of the greedy parser (levels 1-3): a 34 KiB ring (2 KiB chunks) leaves room for
+ * the one-bit-per-position "was inserted" map deflate_fast needs (it does not index the
+ * inside of long matches, src/deflate.c:1940-1962) = 39 936 B, four waves per CU */
+struct LzLdsFast {
+    static constexpr uint32_t RING = 34816u, CHUNK = 2048u;
+    static constexpr bool HAS_INS = true;
+    uint8_t ring[RING + 512];
+    uint32_t stage[WAVE];
+    uint32_t ins[RING / 32];  /* bit r: the position at ring index r is in the hash chains */
+};
 
 typedef struct {
     const uint8_t *in;      /* this buffer */
@@ -62,18 +77,20 @@ typedef struct {
     uint32_t pr_hi;     /* rank/hib are staged in LDS for positions below this */
 } LzState;
 
+template <class L>
 DEV uint32_t lz_ridx(const LzState &st, uint32_t pos)
 {
     uint32_t r = pos - st.wrap_base;
-    return r >= ZD_RING ? r - ZD_RING : r;
+    return r >= L::RING ? r - L::RING : r;
 }
 
 /* bring [hi, hi+CHUNK) into the ring (chunk-aligned, 16 bytes per lane per step) */
-DEV void lz_load_chunk(const LzJob &job, LzLds *lds, LzState &st)
+template <class L>
+DEV void lz_load_chunk(const LzJob &job, L *lds, LzState &st)
 {
-    const uint32_t a0 = st.hi; /* multiple of ZD_CHUNK */
-    const uint32_t r0 = lz_ridx(st, a0);
-    for (uint32_t k = 0; k < ZD_CHUNK; k += WAVE * 16) {
+    const uint32_t a0 = st.hi; /* multiple of CHUNK */
+    const uint32_t r0 = lz_ridx<L>(st, a0);
+    for (uint32_t k = 0; k < L::CHUNK; k += WAVE * 16) {
         FOR_LANES
         {
             uint32_t off = k + (uint32_t)LANE * 16u;
@@ -88,30 +105,40 @@ DEV void lz_load_chunk(const LzJob &job, LzLds *lds, LzState &st)
             }
         }
     }
+    if constexpr (L::HAS_INS) {
+        /* positions that enter the ring have not been inserted into any chain yet */
+        FOR_LANES
+        {
+            if ((uint32_t)LANE < L::CHUNK / 32u)
+                lds->ins[r0 / 32u + (uint32_t)LANE] = 0;
+        }
+    }
     WAVE_SYNC();
     if (r0 == 0) {
         FOR_LANES
         {
             if (LANE < 16)
-                lds->ring[ZD_RING + LANE] = lds->ring[LANE];
+                lds->ring[L::RING + LANE] = lds->ring[LANE];
         }
     }
     WAVE_SYNC();
-    st.hi = a0 + ZD_CHUNK;
-    if (st.hi - st.lo > ZD_RING)
-        st.lo = st.hi - ZD_RING;
-    if (st.lo - st.wrap_base >= ZD_RING)
-        st.wrap_base += ZD_RING;
+    st.hi = a0 + L::CHUNK;
+    if (st.hi - st.lo > L::RING)
+        st.lo = st.hi - L::RING;
+    if (st.lo - st.wrap_base >= L::RING)
+        st.wrap_base += L::RING;
 }
 
 /* make sure the ring holds everything position p can touch: p-32506 .. p+261 */
-DEV void lz_ensure(const LzJob &job, LzLds *lds, LzState &st, uint32_t p)
+template <class L>
+DEV void lz_ensure(const LzJob &job, L *lds, LzState &st, uint32_t p)
 {
     while (st.hi < job.n && st.hi < p + ZD_MIN_LOOKAHEAD)
-        lz_load_chunk(job, lds, st);
+        lz_load_chunk<L>(job, lds, st);
 }
 
-DEV void lz_flush_stage(const LzJob &job, LzLds *lds, LzState &st)
+template <class L>
+DEV void lz_flush_stage(const LzJob &job, L *lds, LzState &st)
 {
     const uint32_t first = st.nsyms - st.nstaged;
     FOR_LANES
@@ -123,14 +150,15 @@ DEV void lz_flush_stage(const LzJob &job, LzLds *lds, LzState &st)
 }
 
 /* _tr_tally_*, reference include/zsc/deflate.h:338-354; returns "block is full" */
-DEV int lz_put(const LzJob &job, LzLds *lds, LzState &st, uint32_t sym)
+template <class L>
+DEV int lz_put(const LzJob &job, L *lds, LzState &st, uint32_t sym)
 {
     ON_LANE0 { lds->stage[st.nstaged] = sym; }
     WAVE_SYNC();
     st.nstaged++;
     st.nsyms++;
     if (st.nstaged == WAVE)
-        lz_flush_stage(job, lds, st);
+        lz_flush_stage<L>(job, lds, st);
     return st.nsyms - st.blk_sym0 == ZD_SYM_CAP;
 }
 
@@ -162,14 +190,15 @@ DEV void lz_refill(const LzJob &job, LzState &st, uint32_t p)
 }
 
 /* cooperative longest-common-prefix of the strings at q and p, at most cap (<=258) bytes */
-DEV uint32_t lz_lcp(const LzLds *lds, const LzState &st, uint32_t q, uint32_t p, uint32_t cap)
+template <class L>
+DEV uint32_t lz_lcp(const L *lds, const LzState &st, uint32_t q, uint32_t p, uint32_t cap)
 {
     LANEVAR(uint32_t, diff);
     LANEVAR(int, differs);
     FOR_LANES
     {
-        uint32_t a = ld_u32(&lds->ring[lz_ridx(st, q + 4u * (uint32_t)LANE)]);
-        uint32_t b = ld_u32(&lds->ring[lz_ridx(st, p + 4u * (uint32_t)LANE)]);
+        uint32_t a = ld_u32(&lds->ring[lz_ridx<L>(st, q + 4u * (uint32_t)LANE)]);
+        uint32_t b = ld_u32(&lds->ring[lz_ridx<L>(st, p + 4u * (uint32_t)LANE)]);
         LV(diff) = a ^ b;
         LV(differs) = LV(diff) != 0;
     }
@@ -181,9 +210,9 @@ DEV uint32_t lz_lcp(const LzLds *lds, const LzState &st, uint32_t q, uint32_t p,
         len = 4u * (uint32_t)f + ((uint32_t)CTZ32(x) >> 3);
     } else {
         len = 256;
-        if (cap > 256 && lds->ring[lz_ridx(st, q + 256)] == lds->ring[lz_ridx(st, p + 256)]) {
+        if (cap > 256 && lds->ring[lz_ridx<L>(st, q + 256)] == lds->ring[lz_ridx<L>(st, p + 256)]) {
             len = 257;
-            if (cap > 257 && lds->ring[lz_ridx(st, q + 257)] == lds->ring[lz_ridx(st, p + 257)])
+            if (cap > 257 && lds->ring[lz_ridx<L>(st, q + 257)] == lds->ring[lz_ridx<L>(st, p + 257)])
                 len = 258;
         }
     }
@@ -191,7 +220,8 @@ DEV uint32_t lz_lcp(const LzLds *lds, const LzState &st, uint32_t q, uint32_t p,
 }
 
 /* stage rank[]/hib[] of the positions ahead of p in LDS (64 per step, coalesced) */
-DEV void lz_ensure_ranks(const LzJob &job, LzLds *lds, LzState &st, uint32_t p)
+template <class L>
+DEV void lz_ensure_ranks(const LzJob &job, L *lds, LzState &st, uint32_t p)
 {
     while (st.pr_hi < job.n && st.pr_hi < p + 384u) {
         FOR_LANES
@@ -229,34 +259,54 @@ typedef struct {
     int head_seen;
 } LzSearch;
 
-/* Evaluate one batch of 64 chain entries (ENT, newest first) that lie in the tile
+/* chain membership of a candidate: the lazy parser indexes every position
+ * (src/deflate.c:2018,2069-2075), the greedy one only those it marked (:1914,1940-1950) */
+#define LZ_MEMB_ALL(q) 1
+#define LZ_MEMB_INS(q) ((lds->ins[lz_ridx<L>(st, (q)) >> 5] >> (lz_ridx<L>(st, (q)) & 31u)) & 1u)
+
+/* Evaluate one batch of 64 sorted entries (ENT, newest first) that lie in the tile
  * starting at TPOS.  Sets `verdict`: 0 continue with the next batch of this run,
  * 1 this run is exhausted, 2 search finished (result in sc), 3 no live chain head. */
-#define LZ_EVAL_BATCH(ENT, TPOS, verdict)                                                     \
+#define LZ_EVAL_BATCH(ENT, TPOS, MEMB, verdict)                                               \
     do {                                                                                      \
         LANEVAR(uint32_t, _q);                                                                \
+        LANEVAR(int, _hok);                                                                   \
         LANEVAR(int, _inb);                                                                   \
         LANEVAR(int, _alive);                                                                 \
         LANEVAR(int, _pass);                                                                  \
         FOR_LANES                                                                             \
         {                                                                                     \
-            LV(_inb) = (LV(ENT) >> 16) == sc.h;                                               \
+            LV(_hok) = (LV(ENT) >> 16) == sc.h;                                               \
             LV(_q) = (TPOS) + (LV(ENT) & ZD_TILE_MASK);                                       \
         }                                                                                     \
-        const uint64_t _m_in = BALLOT(_inb);                                                  \
-        if (!sc.head_seen && !(_m_in & 1ull)) {                                               \
-            (verdict) = 1; /* nothing of this hash in this tile */                            \
+        const uint64_t _m_hash = BALLOT(_hok);                                                \
+        if (!(_m_hash & 1ull)) {                                                              \
+            (verdict) = 1; /* nothing (more) of this hash in this tile */                     \
             break;                                                                            \
         }                                                                                     \
+        LANEVAR(int, _reach); /* near enough to be in the window (and so in the LDS ring) */    \
         FOR_LANES                                                                             \
         {                                                                                     \
-            uint32_t _d = sc.p - LV(_q);                                                      \
-            int _near = _d < ZD_MAX_DIST || (_d == ZD_MAX_DIST && !sc.head_seen && LANE == 0); \
-            LV(_alive) = LV(_inb) && LV(_q) > st.base && _near;                               \
+            LV(_reach) = LV(_hok) && LV(_q) > st.base && sc.p - LV(_q) <= ZD_MAX_DIST;        \
+            LV(_inb) = LV(_reach) && MEMB(LV(_q));                                            \
+        }                                                                                     \
+        const uint64_t _m_reach = BALLOT(_reach);                                             \
+        const uint64_t _m_in = BALLOT(_inb);                                                  \
+        const int _head_lane = (!sc.head_seen && _m_in) ? CTZ64(_m_in) : 64;                  \
+        FOR_LANES                                                                             \
+        {                                                                                     \
+            LV(_alive) = LV(_inb) && (sc.p - LV(_q) < ZD_MAX_DIST || LANE == _head_lane);     \
         }                                                                                     \
         const uint64_t _m_alive = BALLOT(_alive);                                             \
         if (!sc.head_seen) {                                                                  \
-            if (!(_m_alive & 1ull)) {                                                         \
+            if (_m_in == 0) {                                                                 \
+                if (_m_hash & ~_m_reach)                                                      \
+                    (verdict) = 3; /* whatever heads the chain is NIL or too far */           \
+                else /* bucket entries, but none of them is in the chain: keep looking */     \
+                    (verdict) = _m_hash != ~0ull ? 1 : 0;                                     \
+                break;                                                                        \
+            }                                                                                 \
+            if (!((_m_alive >> _head_lane) & 1ull)) {                                         \
                 (verdict) = 3; /* chain head is NIL or too far: longest_match not called */   \
                 break;                                                                        \
             }                                                                                 \
@@ -265,15 +315,15 @@ typedef struct {
                 (verdict) = 2;                                                                \
                 break;                                                                        \
             }                                                                                 \
-            sc.sb = ld_u16(&lds->ring[lz_ridx(st, sc.p + sc.best - 1)]);                      \
+            sc.sb = ld_u16(&lds->ring[lz_ridx<L>(st, sc.p + sc.best - 1)]);                   \
         }                                                                                     \
-        const int _ends = (_m_in & ~_m_alive) != 0; /* a chain member out of reach */         \
+        const int _ends = ((_m_hash & ~_m_reach) | (_m_in & ~_m_alive)) != 0; /* chain leaves the window */         \
         FOR_LANES                                                                             \
         {                                                                                     \
             int _c = 0;                                                                       \
             if (LV(_alive)) {                                                                 \
-                _c = ld_u16(&lds->ring[lz_ridx(st, LV(_q))]) == sc.s01 &&                     \
-                     ld_u16(&lds->ring[lz_ridx(st, LV(_q) + sc.best - 1)]) == sc.sb;          \
+                _c = ld_u16(&lds->ring[lz_ridx<L>(st, LV(_q))]) == sc.s01 &&                  \
+                     ld_u16(&lds->ring[lz_ridx<L>(st, LV(_q) + sc.best - 1)]) == sc.sb;       \
             }                                                                                 \
             LV(_pass) = _c;                                                                   \
         }                                                                                     \
@@ -282,7 +332,7 @@ typedef struct {
         while (_todo != 0) {                                                                  \
             const int _j = CTZ64(_todo);                                                      \
             const uint32_t _qj = READLANE(_q, _j);                                            \
-            const uint32_t _len = lz_lcp(lds, st, _qj, sc.p, sc.cap);                         \
+            const uint32_t _len = lz_lcp<L>(lds, st, _qj, sc.p, sc.cap);                      \
             if (_len > sc.best) {                                                             \
                 sc.where = _qj;                                                               \
                 sc.best = _len;                                                               \
@@ -290,13 +340,13 @@ typedef struct {
                     (verdict) = 2;                                                            \
                     break;                                                                    \
                 }                                                                             \
-                sc.sb = ld_u16(&lds->ring[lz_ridx(st, sc.p + sc.best - 1)]);                  \
+                sc.sb = ld_u16(&lds->ring[lz_ridx<L>(st, sc.p + sc.best - 1)]);               \
                 FOR_LANES                                                                     \
                 {                                                                             \
                     int _c = 0;                                                               \
                     if (LV(_alive) && LANE > _j) {                                            \
-                        _c = ld_u16(&lds->ring[lz_ridx(st, LV(_q))]) == sc.s01 &&             \
-                             ld_u16(&lds->ring[lz_ridx(st, LV(_q) + sc.best - 1)]) == sc.sb;  \
+                        _c = ld_u16(&lds->ring[lz_ridx<L>(st, LV(_q))]) == sc.s01 &&          \
+                             ld_u16(&lds->ring[lz_ridx<L>(st, LV(_q) + sc.best - 1)]) == sc.sb; \
                     }                                                                         \
                     LV(_pass) = _c;                                                           \
                 }                                                                             \
@@ -312,7 +362,7 @@ typedef struct {
         if ((verdict) == 0) {                                                                 \
             if (_ends)                                                                        \
                 (verdict) = 2;                                                                \
-            else if (_m_in != ~0ull)                                                          \
+            else if (_m_hash != ~0ull)                                                        \
                 (verdict) = 1; /* bucket (or tile) exhausted */                               \
         }                                                                                     \
     } while (0)
@@ -320,7 +370,7 @@ typedef struct {
 /* Walk the rest of one run (batches after the first) in groups of four batches:
  * four independent coalesced loads are in flight together, so a long chain costs
  * one memory round trip per 256 candidates instead of one per 64. */
-#define LZ_WALK_RUN(RUN, HI, TPOS, verdict)                                                   \
+#define LZ_WALK_RUN(RUN, HI, TPOS, MEMB, verdict)                                                  \
     do {                                                                                      \
         int32_t _hi = (HI)-WAVE;                                                              \
         while ((verdict) == 0 && _hi >= 0) {                                                  \
@@ -336,13 +386,13 @@ typedef struct {
                 LV(_g2) = _i >= 128 ? (RUN)[_i - 128] : ZD_ENTRY_NONE;                        \
                 LV(_g3) = _i >= 192 ? (RUN)[_i - 192] : ZD_ENTRY_NONE;                        \
             }                                                                                 \
-            LZ_EVAL_BATCH(_g0, TPOS, verdict);                                                \
+            LZ_EVAL_BATCH(_g0, TPOS, MEMB, verdict);                                          \
             if ((verdict) == 0)                                                               \
-                LZ_EVAL_BATCH(_g1, TPOS, verdict);                                            \
+                LZ_EVAL_BATCH(_g1, TPOS, MEMB, verdict);                                      \
             if ((verdict) == 0)                                                               \
-                LZ_EVAL_BATCH(_g2, TPOS, verdict);                                            \
+                LZ_EVAL_BATCH(_g2, TPOS, MEMB, verdict);                                      \
             if ((verdict) == 0)                                                               \
-                LZ_EVAL_BATCH(_g3, TPOS, verdict);                                            \
+                LZ_EVAL_BATCH(_g3, TPOS, MEMB, verdict);                                      \
             _hi -= 4 * WAVE;                                                                  \
         }                                                                                     \
         if ((verdict) == 0)                                                                   \
@@ -352,6 +402,7 @@ typedef struct {
 /* deflate_slow, reference src/deflate.c:1989-2122, flush == Z_FINISH */
 DEV void lz_parse_lazy(const LzJob &job, LzLds *lds)
 {
+    typedef LzLds L;
     LzState st;
     st.lo = st.hi = st.wrap_base = 0;
     st.base = 0;
@@ -383,8 +434,8 @@ DEV void lz_parse_lazy(const LzJob &job, LzLds *lds)
             if (look == 0)
                 break;
         }
-        lz_ensure(job, lds, st, p);
-        lz_ensure_ranks(job, lds, st, p);
+        lz_ensure<L>(job, lds, st, p);
+        lz_ensure_ranks<L>(job, lds, st, p);
 
         const uint32_t prev_len = cur_len, prev_at = cur_at;
         const int searching = look >= 3 && prev_len < job.cfg.lazy;
@@ -415,7 +466,7 @@ DEV void lz_parse_lazy(const LzJob &job, LzLds *lds)
         if (searching) {
             LzSearch sc;
             sc.p = p;
-            const uint32_t w0 = ld_u32(&lds->ring[lz_ridx(st, p)]);
+            const uint32_t w0 = ld_u32(&lds->ring[lz_ridx<L>(st, p)]);
             sc.h = (((w0 & 0xff) << 10) ^ (((w0 >> 8) & 0xff) << 5) ^ ((w0 >> 16) & 0xff)) & ZD_HASH_MASK;
             sc.s01 = w0 & 0xffff;
             sc.sb = 0;
@@ -431,16 +482,16 @@ DEV void lz_parse_lazy(const LzJob &job, LzLds *lds)
             const uint32_t *runA = job.sorted + (uint64_t)tile * ZD_TILE;
             int verdict = 0;
             /* own tile: first batch from the slot, the rest in groups of four */
-            LZ_EVAL_BATCH(cA, tile << 15, verdict);
+            LZ_EVAL_BATCH(cA, tile << 15, LZ_MEMB_ALL, verdict);
             if (verdict == 0)
-                LZ_WALK_RUN(runA, (int32_t)lds->prank[p & (LZ_PR - 1)] - 1, tile << 15, verdict);
+                LZ_WALK_RUN(runA, (int32_t)lds->prank[p & (LZ_PR - 1)] - 1, tile << 15, LZ_MEMB_ALL, verdict);
             if (verdict == 1 && tile != 0) {
                 /* older tile */
                 verdict = 0;
-                LZ_EVAL_BATCH(cB, (tile - 1) << 15, verdict);
+                LZ_EVAL_BATCH(cB, (tile - 1) << 15, LZ_MEMB_ALL, verdict);
                 if (verdict == 0)
                     LZ_WALK_RUN(runA - ZD_TILE, (int32_t)(int16_t)lds->phib[p & (LZ_PR - 1)],
-                                (tile - 1) << 15, verdict);
+                                (tile - 1) << 15, LZ_MEMB_ALL, verdict);
             }
             /* verdict 3: the reference would not have called longest_match */
             if (verdict != 3 && sc.head_seen) {
@@ -452,15 +503,15 @@ DEV void lz_parse_lazy(const LzJob &job, LzLds *lds)
             }
         }
         if (prev_len >= 3 && cur_len <= prev_len) {
-            const int full = lz_put(job, lds, st, ((p - 1 - prev_at) << 16) | (prev_len - 3));
+            const int full = lz_put<L>(job, lds, st, ((p - 1 - prev_at) << 16) | (prev_len - 3));
             pending = 0;
             cur_len = 2;
             p += prev_len - 1;
             if (full)
                 lz_cut(job, st, p, 0);
         } else if (pending) {
-            const uint32_t c = lds->ring[lz_ridx(st, p - 1)];
-            if (lz_put(job, lds, st, c))
+            const uint32_t c = lds->ring[lz_ridx<L>(st, p - 1)];
+            if (lz_put<L>(job, lds, st, c))
                 lz_cut(job, st, p, 0);
             p++;
         } else {
@@ -469,10 +520,106 @@ DEV void lz_parse_lazy(const LzJob &job, LzLds *lds)
         }
     }
     if (pending)
-        (void)lz_put(job, lds, st, lds->ring[lz_ridx(st, p - 1)]);
+        (void)lz_put<L>(job, lds, st, lds->ring[lz_ridx<L>(st, p - 1)]);
     lz_cut(job, st, p, 1);
     if (st.nstaged)
-        lz_flush_stage(job, lds, st);
+        lz_flush_stage<L>(job, lds, st);
+    ON_LANE0
+    {
+        job.out->nsyms = st.nsyms;
+        job.out->nblocks = st.nblocks;
+    }
+}
+
+/* mark position x as inserted into its hash chain (greedy parser) */
+template <class L>
+DEV void lz_mark_inserted(L *lds, const LzState &st, uint32_t x)
+{
+    const uint32_t r = lz_ridx<L>(st, x);
+    ON_LANE0 { lds->ins[r >> 5] |= 1u << (r & 31u); }
+    WAVE_SYNC();
+}
+
+/* deflate_fast, reference src/deflate.c:1886-1982 (levels 1-3), flush == Z_FINISH.
+ * Same candidate machinery as the lazy parser; a candidate belongs to the chain only
+ * if the parse inserted it (short matches index their interior, long ones do not). */
+DEV void lz_parse_greedy(const LzJob &job, LzLdsFast *lds)
+{
+    typedef LzLdsFast L;
+    LzState st;
+    st.lo = st.hi = st.wrap_base = 0;
+    st.base = 0;
+    st.data_end = 0;
+    st.nsyms = st.nstaged = 0;
+    st.nblocks = st.blk_sym0 = st.blk_in0 = 0;
+    st.pr_hi = 0;
+
+    uint32_t p = 0, len = 0, at = 0;
+    for (;;) {
+        uint32_t look = st.data_end - p;
+        if (look < ZD_MIN_LOOKAHEAD) {
+            lz_refill(job, st, p);
+            look = st.data_end - p;
+            if (look == 0)
+                break;
+        }
+        lz_ensure<L>(job, lds, st, p);
+
+        if (look >= 3) {
+            lz_mark_inserted<L>(lds, st, p);
+            LzSearch sc;
+            sc.p = p;
+            const uint32_t w0 = ld_u32(&lds->ring[lz_ridx<L>(st, p)]);
+            sc.h = (((w0 & 0xff) << 10) ^ (((w0 >> 8) & 0xff) << 5) ^ ((w0 >> 16) & 0xff)) & ZD_HASH_MASK;
+            sc.s01 = w0 & 0xffff;
+            sc.sb = 0;
+            sc.look = look;
+            sc.cap = look < 258u ? look : 258u;
+            sc.nice = job.cfg.nice < look ? job.cfg.nice : look;
+            sc.best = 2; /* prev_length stays MIN_MATCH-1 in deflate_fast */
+            sc.budget = 2 >= job.cfg.good ? job.cfg.chain >> 2 : job.cfg.chain;
+            sc.where = at;
+            sc.head_seen = 0;
+
+            const uint32_t tile = p >> 15;
+            const uint32_t *runA = job.sorted + (uint64_t)tile * ZD_TILE;
+            const int32_t hiA = (int32_t)job.rank[p] - 1;
+            const int32_t hiB = tile ? (int32_t)(int16_t)job.hib[p] : -1;
+            int verdict = 0;
+            LZ_WALK_RUN(runA, hiA + WAVE, tile << 15, LZ_MEMB_INS, verdict);
+            if (verdict == 1 && tile != 0) {
+                verdict = 0;
+                LZ_WALK_RUN(runA - ZD_TILE, hiB + WAVE, (tile - 1) << 15, LZ_MEMB_INS, verdict);
+            }
+            if (verdict != 3 && sc.head_seen) {
+                at = sc.where;
+                len = sc.best < look ? sc.best : look;
+            }
+        }
+        int full;
+        if (len >= 3) {
+            full = lz_put<L>(job, lds, st, ((p - at) << 16) | (len - 3));
+            look -= len;
+            if (len <= job.cfg.lazy /* max_insert_length */ && look >= 3) {
+                for (len--; len != 0; len--) {
+                    p++;
+                    lz_mark_inserted<L>(lds, st, p);
+                }
+                p++;
+            } else {
+                p += len;
+                len = 0;
+            }
+        } else {
+            full = lz_put<L>(job, lds, st, lds->ring[lz_ridx<L>(st, p)]);
+            p++;
+        }
+        if (full)
+            lz_cut(job, st, p, 0);
+    }
+    lz_cut(job, st, p, 1);
+    if (st.nstaged)
+        lz_flush_stage<L>(job, lds, st);
     ON_LANE0
     {
         job.out->nsyms = st.nsyms;

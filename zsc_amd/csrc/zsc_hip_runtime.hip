@@ -144,6 +144,37 @@ __global__ __launch_bounds__(64) void k_parse(const uint8_t *__restrict__ in,
     lz_parse_lazy(job, &lds);
 }
 
+/* kernel 2 for levels 1-3 (greedy parse) */
+__global__ __launch_bounds__(64) void k_parse_fast(const uint8_t *__restrict__ in,
+                                                   const ZdBuf *__restrict__ bufs,
+                                                   const uint32_t *__restrict__ order,
+                                                   const uint32_t *__restrict__ sorted,
+                                                   const uint16_t *__restrict__ rank,
+                                                   const uint16_t *__restrict__ hib,
+                                                   uint32_t *__restrict__ syms,
+                                                   ZdBlockRec *__restrict__ recs,
+                                                   ZdParseOut *__restrict__ pout,
+                                                   const ZdLevel cfg, uint32_t nbuf)
+{
+    __shared__ LzLdsFast lds;
+    if (blockIdx.x >= nbuf)
+        return;
+    const uint32_t b = order[blockIdx.x];
+    const ZdBuf buf = bufs[b];
+    LzJob job;
+    job.in = in + buf.in_off;
+    job.n = buf.in_len;
+    job.sorted = sorted + (uint64_t)buf.tile0 * ZD_TILE;
+    job.rank = rank + buf.rank_off;
+    job.hib = hib + buf.rank_off;
+    job.syms = syms + buf.sym_off;
+    job.blocks = recs + buf.blk0;
+    job.out = pout + b;
+    job.cfg = cfg;
+    job.strategy = buf.strategy;
+    lz_parse_greedy(job, &lds);
+}
+
 /* kernel 3: one wavefront per (possible) block */
 __global__ __launch_bounds__(64) void k_huff_plan(const ZdBuf *__restrict__ bufs,
                                                   const uint32_t *__restrict__ blk_owner,
@@ -371,7 +402,7 @@ static bool offloadable(I32 level, I32 window_bits, I32 mem_level, ZlibStrategy 
     }
     if (level == Z_DEFAULT_COMPRESSION)
         level = 6;
-    return wb == 15 && mem_level == 8 && level >= 4 && level <= 9 &&
+    return wb == 15 && mem_level == 8 && level >= 1 && level <= 9 &&
            (strategy == Z_DEFAULT_STRATEGY || strategy == Z_FILTERED || strategy == Z_FIXED);
 }
 
@@ -599,10 +630,16 @@ extern "C" ZlibReturn zsc_hip_deflate_plan_run(zsc_hip_deflate_plan *pl, const v
                            (const uint32_t *)sb.d_tile_owner.p, (const uint16_t *)dir, hib,
                            sb.ntiles);
         mark();
-        hipLaunchKernelGGL(k_parse, dim3(sb.count), dim3(64), 0, st, in, bufs,
-                           (const uint32_t *)sb.d_order.p, (const uint32_t *)sorted,
-                           (const uint16_t *)rank, (const uint16_t *)hib, tmp_syms, recs, pout,
-                           cfg, sb.count);
+        if (cfg.slow)
+            hipLaunchKernelGGL(k_parse, dim3(sb.count), dim3(64), 0, st, in, bufs,
+                               (const uint32_t *)sb.d_order.p, (const uint32_t *)sorted,
+                               (const uint16_t *)rank, (const uint16_t *)hib, tmp_syms, recs,
+                               pout, cfg, sb.count);
+        else
+            hipLaunchKernelGGL(k_parse_fast, dim3(sb.count), dim3(64), 0, st, in, bufs,
+                               (const uint32_t *)sb.d_order.p, (const uint32_t *)sorted,
+                               (const uint16_t *)rank, (const uint16_t *)hib, tmp_syms, recs,
+                               pout, cfg, sb.count);
         mark();
         hipLaunchKernelGGL(k_huff_plan, dim3(sb.nslots), dim3(64), 0, st, bufs,
                            (const uint32_t *)sb.d_blk_owner.p, (const uint32_t *)tmp_syms,
