@@ -85,6 +85,8 @@ def main() -> None:
     ap.add_argument("--level", type=int, default=6)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--verify", type=int, default=1, help="buffers per rank checked against the oracle")
+    ap.add_argument("--with-inflate", action="store_true",
+                    help="also time the inflate kernel on the produced streams (extra field)")
     args = ap.parse_args()
 
     import torch
@@ -181,6 +183,29 @@ def main() -> None:
         if rc != 0 or got != want:
             raise SystemExit(f"rank {rank}: buffer {k} differs from the oracle")
 
+    # ---- inflate of the streams just produced (reported beside the headline, not part of it)
+    inflate_info = None
+    if args.with_inflate:
+        ip = zsc_amd.InflatePlan(lens, my_lens)
+        d_src = torch.zeros(ip.src_bytes, dtype=torch.uint8, device=dev)
+        for i in range(len(lens)):  # device-to-device staging into the inflate layout (untimed)
+            d_src[ip.src_offsets[i]:ip.src_offsets[i] + lens[i]] = d_out[plan.out_offsets[i]:plan.out_offsets[i] + lens[i]]
+        d_dst = torch.empty(ip.dst_bytes, dtype=torch.uint8, device=dev)
+        ip.run(d_src.data_ptr(), d_dst.data_ptr(), stream); ip.results()
+        fence()
+        t1 = time.perf_counter()
+        ip.run(d_src.data_ptr(), d_dst.data_ptr(), stream)
+        fence()
+        wall = time.perf_counter() - t1
+        olens, used, istat, kms = ip.results()
+        ok = all(s == 0 for s in istat) and olens == list(my_lens) and used == list(lens)
+        chk = bytes(d_dst[ip.dst_offsets[2]:ip.dst_offsets[2] + my_lens[2]].cpu().numpy()) == period_bufs[2]
+        inflate_info = {"MB_per_s_out": round(in_bytes_rank / wall / 1e6, 2), "kernel_ms": round(kms, 3),
+                        "wall_ms": round(wall * 1e3, 3), "all_ok": bool(ok and chk),
+                        "note": "zsc_uncompress semantics, one wave per stream, this rank only"}
+        ip.close()
+        del d_src, d_dst
+
     if rank == 0:
         total_in = sum(all_lens)
         total_out = sum(all_sizes)
@@ -211,6 +236,18 @@ def main() -> None:
             "scratch_bytes": plan.scratch_bytes,
             "device": zsc_amd.device_info(),
         }
+        # HBM traffic of the dominant kernel from rocprofv3 --pmc passes (profiles/pmc_traffic.json),
+        # scaled by input bytes when the PMC run used a smaller batch of the same workload
+        try:
+            pmc = json.load(open(os.path.join(ROOT, "profiles", "pmc_traffic.json")))
+            if pmc.get("level") == args.level:
+                scale = in_bytes_rank / pmc["input_bytes"]
+                line["roofline"]["traffic"] = round((pmc["fetch_kb"] + pmc["write_kb"]) * 1024 * scale)
+                line["roofline"]["traffic_note"] = pmc["note"]
+        except Exception:
+            pass
+        if inflate_info:
+            line["inflate"] = inflate_info
         if not args.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline(args.level)
         print(json.dumps(line), flush=True)

@@ -79,10 +79,28 @@ static void build_chains(EmuChains &c, const uint8_t *src, uint32_t n)
 static void run_parse(const LzJob &job)
 {
     if (job.cfg.slow) {
-        LzLds *lds = (LzLds *)malloc(sizeof(LzLds));
-        memset(lds, 0xA5, sizeof(LzLds));
-        lz_parse_lazy(job, lds);
-        free(lds);
+        /* the ring class the runtime would pick for this length */
+        if (job.n > 18432u) {
+            LzLds *lds = (LzLds *)malloc(sizeof(LzLds));
+            memset(lds, 0xA5, sizeof(LzLds));
+            lz_parse_lazy<LzLds>(job, lds);
+            free(lds);
+        } else if (job.n > 10240u) {
+            LzLds16k *lds = (LzLds16k *)malloc(sizeof(LzLds16k));
+            memset(lds, 0xA5, sizeof(LzLds16k));
+            lz_parse_lazy<LzLds16k>(job, lds);
+            free(lds);
+        } else if (job.n > 6144u) {
+            LzLds8k *lds = (LzLds8k *)malloc(sizeof(LzLds8k));
+            memset(lds, 0xA5, sizeof(LzLds8k));
+            lz_parse_lazy<LzLds8k>(job, lds);
+            free(lds);
+        } else {
+            LzLds4k *lds = (LzLds4k *)malloc(sizeof(LzLds4k));
+            memset(lds, 0xA5, sizeof(LzLds4k));
+            lz_parse_lazy<LzLds4k>(job, lds);
+            free(lds);
+        }
     } else {
         LzLdsFast *lds = (LzLdsFast *)malloc(sizeof(LzLdsFast));
         memset(lds, 0xA5, sizeof(LzLdsFast));

@@ -33,14 +33,21 @@
 
 /* LDS of the lazy parser (levels 4-9): 36 KiB window ring + look-ahead rings = 39 680 B,
  * four waves per CU */
-struct LzLds {
-    static constexpr uint32_t RING = ZD_RING, CHUNK = ZD_CHUNK;
+template <uint32_t RING_BYTES, uint32_t CHUNK_BYTES>
+struct LzLdsT {
+    static constexpr uint32_t RING = RING_BYTES, CHUNK = CHUNK_BYTES;
     static constexpr bool HAS_INS = false;
     uint8_t ring[RING + 512]; /* sliding window; first 16 bytes mirrored after the end, rest slack for masked over-reads */
     uint32_t stage[WAVE];     /* symbols waiting for a coalesced store */
     uint16_t prank[LZ_PR];    /* rank[] of the next few hundred positions */
     uint16_t phib[LZ_PR];     /* hib[] of the same positions */
 };
+typedef LzLdsT<ZD_RING, ZD_CHUNK> LzLds;
+/* a buffer that fits the ring whole never slides it, so short buffers can run with a
+ * smaller ring and proportionally more waves per CU (the parser is latency-bound) */
+typedef LzLdsT<18432u, 2048u> LzLds16k; /* n <= 18 432: 7 waves per CU */
+typedef LzLdsT<10240u, 2048u> LzLds8k;  /* n <= 10 240: 12 waves per CU */
+typedef LzLdsT<6144u, 2048u> LzLds4k;   /* n <=  6 144: 17 waves per CU */
 
 /* LDS of the greedy parser (levels 1-3): a 34 KiB ring (2 KiB chunks) leaves room for
  * the one-bit-per-position "was inserted" map deflate_fast needs (it does not index the
@@ -400,9 +407,9 @@ typedef struct {
     } while (0)
 
 /* deflate_slow, reference src/deflate.c:1989-2122, flush == Z_FINISH */
-DEV void lz_parse_lazy(const LzJob &job, LzLds *lds)
+template <class L>
+DEV void lz_parse_lazy(const LzJob &job, L *lds)
 {
-    typedef LzLds L;
     LzState st;
     st.lo = st.hi = st.wrap_base = 0;
     st.base = 0;

@@ -113,7 +113,10 @@ __global__ __launch_bounds__(HS_WAVES * 64) void k_link_prev(
     hs_link_prev(job, (int)(threadIdx.x >> 6));
 }
 
-/* kernel 2: one wavefront per buffer, longest buffers first */
+/* kernel 2: one wavefront per buffer, longest buffers first.  L picks the LDS ring
+ * size (and with it the number of waves a CU can hold); `first`/`nbuf` select the
+ * slice of the length-sorted order this launch covers. */
+template <class L>
 __global__ __launch_bounds__(64) void k_parse(const uint8_t *__restrict__ in,
                                               const ZdBuf *__restrict__ bufs,
                                               const uint32_t *__restrict__ order,
@@ -123,12 +126,12 @@ __global__ __launch_bounds__(64) void k_parse(const uint8_t *__restrict__ in,
                                               uint32_t *__restrict__ syms,
                                               ZdBlockRec *__restrict__ recs,
                                               ZdParseOut *__restrict__ pout,
-                                              const ZdLevel cfg, uint32_t nbuf)
+                                              const ZdLevel cfg, uint32_t first, uint32_t nbuf)
 {
-    __shared__ LzLds lds;
+    __shared__ L lds;
     if (blockIdx.x >= nbuf)
         return;
-    const uint32_t b = order[blockIdx.x];
+    const uint32_t b = order[first + blockIdx.x];
     const ZdBuf buf = bufs[b];
     LzJob job;
     job.in = in + buf.in_off;
@@ -141,7 +144,7 @@ __global__ __launch_bounds__(64) void k_parse(const uint8_t *__restrict__ in,
     job.out = pout + b;
     job.cfg = cfg;
     job.strategy = buf.strategy;
-    lz_parse_lazy(job, &lds);
+    lz_parse_lazy<L>(job, &lds);
 }
 
 /* kernel 2 for levels 1-3 (greedy parse) */
@@ -351,6 +354,9 @@ struct SubBatch {
     uint32_t ntiles = 0, nslots = 0;
     uint64_t nsym_slots = 0;
     DevBuf d_bufs, d_tile_owner, d_blk_owner, d_order;
+    /* the length-sorted order (longest first) splits into ring-size classes:
+     * [0,c36) full ring, [c36,c16) <= 18 432 B, [c16,c8) <= 10 240 B, [c8,count) <= 6 144 B */
+    uint32_t c36 = 0, c16 = 0, c8 = 0;
 };
 
 } // namespace
@@ -464,7 +470,7 @@ extern "C" ZlibReturn zsc_hip_deflate_plan_create(zsc_hip_deflate_plan **plan_ou
     pl->strategy = (uint32_t)strategy;
     pl->bufs.resize(count);
 
-    uint64_t sub_limit = 4096ull << 20; /* input bytes per sub-batch */
+    uint64_t sub_limit = 16384ull << 20; /* input bytes per sub-batch (scratch is ~10 B per input byte) */
     if (const char *e = getenv("ZSC_HIP_SUBBATCH_MB"))
         sub_limit = (uint64_t)atoll(e) << 20;
     if (sub_limit < (1ull << 20))
@@ -528,6 +534,20 @@ extern "C" ZlibReturn zsc_hip_deflate_plan_create(zsc_hip_deflate_plan **plan_ou
         std::stable_sort(order.begin(), order.end(), [&](uint32_t a, uint32_t c) {
             return pl->bufs[sb.first + a].in_len > pl->bufs[sb.first + c].in_len;
         });
+        {
+            const bool full_only = getenv("ZSC_HIP_FULL_RING") != nullptr;
+            uint32_t k = 0;
+            auto len_at = [&](uint32_t idx) { return pl->bufs[sb.first + order[idx]].in_len; };
+            while (k < sb.count && (full_only || len_at(k) > 18432u))
+                k++;
+            sb.c36 = k;
+            while (k < sb.count && len_at(k) > 10240u)
+                k++;
+            sb.c16 = k;
+            while (k < sb.count && len_at(k) > 6144u)
+                k++;
+            sb.c8 = k;
+        }
         bool ok = sb.d_bufs.ensure(sizeof(ZdBuf) * sb.count) &&
                   sb.d_tile_owner.ensure(4ull * std::max(1u, sb.ntiles)) &&
                   sb.d_blk_owner.ensure(4ull * std::max(1u, sb.nslots)) &&
@@ -630,12 +650,19 @@ extern "C" ZlibReturn zsc_hip_deflate_plan_run(zsc_hip_deflate_plan *pl, const v
                            (const uint32_t *)sb.d_tile_owner.p, (const uint16_t *)dir, hib,
                            sb.ntiles);
         mark();
-        if (cfg.slow)
-            hipLaunchKernelGGL(k_parse, dim3(sb.count), dim3(64), 0, st, in, bufs,
-                               (const uint32_t *)sb.d_order.p, (const uint32_t *)sorted,
-                               (const uint16_t *)rank, (const uint16_t *)hib, tmp_syms, recs,
-                               pout, cfg, sb.count);
-        else
+        if (cfg.slow) {
+#define ZSC_LAUNCH_PARSE(LT, FIRST, COUNT)                                                       \
+    if ((COUNT) > 0)                                                                             \
+    hipLaunchKernelGGL(k_parse<LT>, dim3(COUNT), dim3(64), 0, st, in, bufs,                      \
+                       (const uint32_t *)sb.d_order.p, (const uint32_t *)sorted,                 \
+                       (const uint16_t *)rank, (const uint16_t *)hib, tmp_syms, recs, pout, cfg, \
+                       (uint32_t)(FIRST), (uint32_t)(COUNT))
+            ZSC_LAUNCH_PARSE(LzLds, 0, sb.c36);
+            ZSC_LAUNCH_PARSE(LzLds16k, sb.c36, sb.c16 - sb.c36);
+            ZSC_LAUNCH_PARSE(LzLds8k, sb.c16, sb.c8 - sb.c16);
+            ZSC_LAUNCH_PARSE(LzLds4k, sb.c8, sb.count - sb.c8);
+#undef ZSC_LAUNCH_PARSE
+        } else
             hipLaunchKernelGGL(k_parse_fast, dim3(sb.count), dim3(64), 0, st, in, bufs,
                                (const uint32_t *)sb.d_order.p, (const uint32_t *)sorted,
                                (const uint16_t *)rank, (const uint16_t *)hib, tmp_syms, recs,
