@@ -16,6 +16,7 @@ struct uint4 { uint32_t x, y, z, w; };
 
 #include "../../zsc_amd/csrc/hash_sort.h"
 #include "../../zsc_amd/csrc/lz_parse.h"
+#include "../../zsc_amd/csrc/lz_parse_seg.h"
 #include "../../zsc_amd/csrc/huff_plan.h"
 #include "../../zsc_amd/csrc/bit_emit.h"
 #include "../../zsc_amd/csrc/checksum.h"
@@ -76,8 +77,42 @@ static void build_chains(EmuChains &c, const uint8_t *src, uint32_t n)
     }
 }
 
+int g_seg_mode = 0; /* 0: runtime's choice, 1: force wave-per-buffer, 2: segmented + successors parse first,
+                       3: segmented + predecessors first (no hand-over is ever found in time) */
+extern "C" void emu_set_seg_mode(int m) { g_seg_mode = m; }
+
+static void run_parse_seg(const LzJob &job, int order)
+{
+    SgLds *lds = (SgLds *)malloc(sizeof(SgLds));
+    memset(lds, 0x6B, sizeof(SgLds));
+    std::vector<uint32_t> tok((size_t)SG_W * SG_TOKCAP, 0xDDDDDDDD);
+    std::vector<uint16_t> sidx((size_t)SG_W * SG_TRACE, 0xDDDD);
+    SgScratch scr = {tok.data(), sidx.data()};
+    for (int w = 0; w < SG_W; w++)
+        sg_init(lds, w);
+    while (!lds->finished) {
+        for (int w = 0; w < SG_W; w++)
+            sg_phase_begin(job, lds, w);
+        do {
+            if (order == 2)
+                for (int w = SG_W - 1; w >= 0; w--)
+                    sg_phase_parse(job, lds, scr, w);
+            else
+                for (int w = 0; w < SG_W; w++)
+                    sg_phase_parse(job, lds, scr, w);
+            for (int w = 0; w < SG_W; w++)
+                sg_phase_resolve(job, lds, scr, w);
+        } while (lds->again);
+    }
+    free(lds);
+}
+
 static void run_parse(const LzJob &job)
 {
+    if (job.cfg.slow && (g_seg_mode >= 2 || (g_seg_mode == 0 && job.n > 18432u))) {
+        run_parse_seg(job, g_seg_mode == 3 ? 3 : 2);
+        return;
+    }
     if (job.cfg.slow) {
         /* the ring class the runtime would pick for this length */
         if (job.n > 18432u) {

@@ -297,6 +297,11 @@ DEV void emit_block(const uint8_t *in, const uint32_t *syms, const ZdBlockRec *r
 DEV void layout_buffer(const ZdBuf *buf, const ZdParseOut *po, const ZdBlockRec *recs,
                        ZdBlockPlan *plans, ZdResult *res, uint8_t *out)
 {
+    if (po->nblocks > buf->max_blocks) {
+        res->status = -2; /* the parser gave up (cannot happen unless there is a bug): fail loudly */
+        res->out_len = 0;
+        return;
+    }
     const uint32_t hdr_bytes = buf->wrap == 1 ? 2u : buf->wrap == 2 ? 10u : 0u;
     const uint32_t trl_bytes = buf->wrap == 1 ? 4u : buf->wrap == 2 ? 8u : 0u;
     uint32_t bit = hdr_bytes * 8u;

@@ -217,9 +217,9 @@ DEV uint32_t lz_lcp(const L *lds, const LzState &st, uint32_t q, uint32_t p, uin
         len = 4u * (uint32_t)f + ((uint32_t)CTZ32(x) >> 3);
     } else {
         len = 256;
-        if (cap > 256 && lds->ring[lz_ridx<L>(st, q + 256)] == lds->ring[lz_ridx<L>(st, p + 256)]) {
+        if (cap > 256 && UNI(lds->ring[lz_ridx<L>(st, q + 256)]) == UNI(lds->ring[lz_ridx<L>(st, p + 256)])) {
             len = 257;
-            if (cap > 257 && lds->ring[lz_ridx<L>(st, q + 257)] == lds->ring[lz_ridx<L>(st, p + 257)])
+            if (cap > 257 && UNI(lds->ring[lz_ridx<L>(st, q + 257)]) == UNI(lds->ring[lz_ridx<L>(st, p + 257)]))
                 len = 258;
         }
     }
@@ -249,8 +249,8 @@ DEV void lz_ensure_ranks(const LzJob &job, L *lds, LzState &st, uint32_t p)
     do {                                                                                      \
         const uint32_t _t = (x) >> 15;                                                        \
         const uint32_t *_ra = job.sorted + (uint64_t)_t * ZD_TILE;                            \
-        const int32_t _ha = (int32_t)lds->prank[(x) & (LZ_PR - 1)] - 1;                       \
-        const int32_t _hb = _t ? (int32_t)(int16_t)lds->phib[(x) & (LZ_PR - 1)] : -1;         \
+        const int32_t _ha = (int32_t)UNI(lds->prank[(x) & (LZ_PR - 1)]) - 1;                  \
+        const int32_t _hb = _t ? (int32_t)(int16_t)UNI(lds->phib[(x) & (LZ_PR - 1)]) : -1;    \
         FOR_LANES                                                                             \
         {                                                                                     \
             int32_t _ia = _ha - LANE, _ib = _hb - LANE;                                       \
@@ -322,7 +322,7 @@ typedef struct {
                 (verdict) = 2;                                                                \
                 break;                                                                        \
             }                                                                                 \
-            sc.sb = ld_u16(&lds->ring[lz_ridx<L>(st, sc.p + sc.best - 1)]);                   \
+            sc.sb = UNI(ld_u16(&lds->ring[lz_ridx<L>(st, sc.p + sc.best - 1)]));              \
         }                                                                                     \
         const int _ends = ((_m_hash & ~_m_reach) | (_m_in & ~_m_alive)) != 0; /* chain leaves the window */         \
         FOR_LANES                                                                             \
@@ -347,7 +347,7 @@ typedef struct {
                     (verdict) = 2;                                                            \
                     break;                                                                    \
                 }                                                                             \
-                sc.sb = ld_u16(&lds->ring[lz_ridx<L>(st, sc.p + sc.best - 1)]);               \
+                sc.sb = UNI(ld_u16(&lds->ring[lz_ridx<L>(st, sc.p + sc.best - 1)]));          \
                 FOR_LANES                                                                     \
                 {                                                                             \
                     int _c = 0;                                                               \
@@ -473,7 +473,7 @@ DEV void lz_parse_lazy(const LzJob &job, L *lds)
         if (searching) {
             LzSearch sc;
             sc.p = p;
-            const uint32_t w0 = ld_u32(&lds->ring[lz_ridx<L>(st, p)]);
+            const uint32_t w0 = UNI(ld_u32(&lds->ring[lz_ridx<L>(st, p)]));
             sc.h = (((w0 & 0xff) << 10) ^ (((w0 >> 8) & 0xff) << 5) ^ ((w0 >> 16) & 0xff)) & ZD_HASH_MASK;
             sc.s01 = w0 & 0xffff;
             sc.sb = 0;
@@ -491,13 +491,13 @@ DEV void lz_parse_lazy(const LzJob &job, L *lds)
             /* own tile: first batch from the slot, the rest in groups of four */
             LZ_EVAL_BATCH(cA, tile << 15, LZ_MEMB_ALL, verdict);
             if (verdict == 0)
-                LZ_WALK_RUN(runA, (int32_t)lds->prank[p & (LZ_PR - 1)] - 1, tile << 15, LZ_MEMB_ALL, verdict);
+                LZ_WALK_RUN(runA, (int32_t)UNI(lds->prank[p & (LZ_PR - 1)]) - 1, tile << 15, LZ_MEMB_ALL, verdict);
             if (verdict == 1 && tile != 0) {
                 /* older tile */
                 verdict = 0;
                 LZ_EVAL_BATCH(cB, (tile - 1) << 15, LZ_MEMB_ALL, verdict);
                 if (verdict == 0)
-                    LZ_WALK_RUN(runA - ZD_TILE, (int32_t)(int16_t)lds->phib[p & (LZ_PR - 1)],
+                    LZ_WALK_RUN(runA - ZD_TILE, (int32_t)(int16_t)UNI(lds->phib[p & (LZ_PR - 1)]),
                                 (tile - 1) << 15, LZ_MEMB_ALL, verdict);
             }
             /* verdict 3: the reference would not have called longest_match */
@@ -517,7 +517,7 @@ DEV void lz_parse_lazy(const LzJob &job, L *lds)
             if (full)
                 lz_cut(job, st, p, 0);
         } else if (pending) {
-            const uint32_t c = lds->ring[lz_ridx<L>(st, p - 1)];
+            const uint32_t c = UNI(lds->ring[lz_ridx<L>(st, p - 1)]);
             if (lz_put<L>(job, lds, st, c))
                 lz_cut(job, st, p, 0);
             p++;
@@ -527,7 +527,7 @@ DEV void lz_parse_lazy(const LzJob &job, L *lds)
         }
     }
     if (pending)
-        (void)lz_put<L>(job, lds, st, lds->ring[lz_ridx<L>(st, p - 1)]);
+        (void)lz_put<L>(job, lds, st, UNI(lds->ring[lz_ridx<L>(st, p - 1)]));
     lz_cut(job, st, p, 1);
     if (st.nstaged)
         lz_flush_stage<L>(job, lds, st);
@@ -576,7 +576,7 @@ DEV void lz_parse_greedy(const LzJob &job, LzLdsFast *lds)
             lz_mark_inserted<L>(lds, st, p);
             LzSearch sc;
             sc.p = p;
-            const uint32_t w0 = ld_u32(&lds->ring[lz_ridx<L>(st, p)]);
+            const uint32_t w0 = UNI(ld_u32(&lds->ring[lz_ridx<L>(st, p)]));
             sc.h = (((w0 & 0xff) << 10) ^ (((w0 >> 8) & 0xff) << 5) ^ ((w0 >> 16) & 0xff)) & ZD_HASH_MASK;
             sc.s01 = w0 & 0xffff;
             sc.sb = 0;
@@ -590,8 +590,8 @@ DEV void lz_parse_greedy(const LzJob &job, LzLdsFast *lds)
 
             const uint32_t tile = p >> 15;
             const uint32_t *runA = job.sorted + (uint64_t)tile * ZD_TILE;
-            const int32_t hiA = (int32_t)job.rank[p] - 1;
-            const int32_t hiB = tile ? (int32_t)(int16_t)job.hib[p] : -1;
+            const int32_t hiA = (int32_t)UNI(job.rank[p]) - 1;
+            const int32_t hiB = tile ? (int32_t)(int16_t)UNI(job.hib[p]) : -1;
             int verdict = 0;
             LZ_WALK_RUN(runA, hiA + WAVE, tile << 15, LZ_MEMB_INS, verdict);
             if (verdict == 1 && tile != 0) {
@@ -618,7 +618,7 @@ DEV void lz_parse_greedy(const LzJob &job, LzLdsFast *lds)
                 len = 0;
             }
         } else {
-            full = lz_put<L>(job, lds, st, lds->ring[lz_ridx<L>(st, p)]);
+            full = lz_put<L>(job, lds, st, UNI(lds->ring[lz_ridx<L>(st, p)]));
             p++;
         }
         if (full)

@@ -98,6 +98,7 @@ static inline uint32_t ld_u16(const uint8_t *p)
 #define CTZ32(x) __builtin_ctz(x)
 #define POPC64(x) __builtin_popcountll(x)
 #define COPY16(dst, src) memcpy((dst), (src), 16)
+#define UNI(x) (x)
 
 #else
 /* ---------------------------------------------------------------- gfx950 */
@@ -170,6 +171,11 @@ DEV uint32_t ld_u16(const uint8_t *p)
 #define CTZ64(x) __builtin_ctzll(x)
 #define CTZ32(x) __builtin_ctz(x)
 #define POPC64(x) __builtin_popcountll(x)
+/* A value that is the same in every lane but was produced by a vector instruction
+ * (an LDS or global load from a wave-uniform address): move it to an SGPR, so that
+ * branches on it are scalar branches instead of exec-mask regions and arithmetic on
+ * it runs on the scalar unit. */
+#define UNI(x) ((uint32_t)__builtin_amdgcn_readfirstlane((int)(x)))
 /* both sides 16-byte aligned: one global_load_dwordx4 + one ds_write_b128 */
 #define COPY16(dst, src) (*(uint4 *)(dst) = *(const uint4 *)(src))
 #endif

@@ -25,6 +25,7 @@
 #include "huff_plan.h"
 #include "inflate.h"
 #include "lz_parse.h"
+#include "lz_parse_seg.h"
 #include "zsc_dev.h"
 
 #include "zsc/zsc_conf_private.h"
@@ -147,6 +148,76 @@ __global__ __launch_bounds__(64) void k_parse(const uint8_t *__restrict__ in,
     lz_parse_lazy<L>(job, &lds);
 }
 
+/* kernel 2 for long buffers at levels 4-9: SG_W wavefronts share one window and parse
+ * SG_W segments of the same buffer at once (lz_parse_seg.h) */
+__global__ __launch_bounds__(SG_W * 64, 6) void k_parse_seg(const uint8_t *__restrict__ in,
+                                                         const ZdBuf *__restrict__ bufs,
+                                                         const uint32_t *__restrict__ order,
+                                                         const uint32_t *__restrict__ sorted,
+                                                         const uint16_t *__restrict__ rank,
+                                                         const uint16_t *__restrict__ hib,
+                                                         uint32_t *__restrict__ syms,
+                                                         ZdBlockRec *__restrict__ recs,
+                                                         ZdParseOut *__restrict__ pout,
+                                                         uint32_t *__restrict__ seg_tok,
+                                                         uint16_t *__restrict__ seg_sidx,
+                                                         const ZdLevel cfg, uint32_t first,
+                                                         uint32_t nbuf)
+{
+    __shared__ SgLds lds;
+    if (blockIdx.x >= nbuf)
+        return;
+    const uint32_t b = order[first + blockIdx.x];
+    const ZdBuf buf = bufs[b];
+    LzJob job;
+    job.in = in + buf.in_off;
+    job.n = buf.in_len;
+    job.sorted = sorted + (uint64_t)buf.tile0 * ZD_TILE;
+    job.rank = rank + buf.rank_off;
+    job.hib = hib + buf.rank_off;
+    job.syms = syms + buf.sym_off;
+    job.blocks = recs + buf.blk0;
+    job.out = pout + b;
+    job.cfg = cfg;
+    job.strategy = buf.strategy;
+    SgScratch scr;
+    scr.tok = seg_tok + (uint64_t)blockIdx.x * (SG_W * SG_TOKCAP);
+    scr.sidx = seg_sidx + (uint64_t)blockIdx.x * (SG_W * SG_TRACE);
+    const int w = (int)(threadIdx.x >> 6);
+    sg_init(&lds, w);
+    __syncthreads();
+    /* every loop is bounded so that a logic error can never hang the device: a buffer
+     * needs n/SG_SPAN + 1 super-steps and a super-step at most SG_W parse rounds */
+    const uint32_t max_steps = buf.in_len / SG_SPAN + 2;
+    uint32_t steps = 0;
+    bool stuck = false;
+    while (!lds.finished) {
+        if (++steps > max_steps) {
+            stuck = true;
+            break;
+        }
+        sg_phase_begin(job, &lds, w);
+        __syncthreads();
+        uint32_t rounds = 0;
+        do {
+            if (++rounds > SG_W + 1) {
+                stuck = true;
+                break;
+            }
+            sg_phase_parse(job, &lds, scr, w);
+            __syncthreads();
+            sg_phase_resolve(job, &lds, scr, w);
+            __syncthreads();
+        } while (lds.again);
+        if (stuck)
+            break;
+    }
+    if (stuck && threadIdx.x == 0) {
+        job.out->nsyms = 0;
+        job.out->nblocks = 0xffffffffu; /* reported as Z_STREAM_ERROR by the layout kernel */
+    }
+}
+
 /* kernel 2 for levels 1-3 (greedy parse) */
 __global__ __launch_bounds__(64) void k_parse_fast(const uint8_t *__restrict__ in,
                                                    const ZdBuf *__restrict__ bufs,
@@ -192,7 +263,7 @@ __global__ __launch_bounds__(64) void k_huff_plan(const ZdBuf *__restrict__ bufs
         return;
     const uint32_t b = blk_owner[slot];
     const ZdBuf buf = bufs[b];
-    if (slot - buf.blk0 >= pout[b].nblocks)
+    if (slot - buf.blk0 >= pout[b].nblocks || pout[b].nblocks > buf.max_blocks)
         return;
     const ZdBlockRec *rec = &recs[slot];
     huff_plan_block(syms + buf.sym_off + rec->sym_begin, rec, buf.strategy, &plans[slot], &lds);
@@ -229,7 +300,7 @@ __global__ __launch_bounds__(64) void k_emit(const uint8_t *__restrict__ in,
         return;
     const uint32_t b = blk_owner[slot];
     const ZdBuf buf = bufs[b];
-    if (slot - buf.blk0 >= pout[b].nblocks)
+    if (slot - buf.blk0 >= pout[b].nblocks || pout[b].nblocks > buf.max_blocks)
         return;
     const ZdBlockRec *rec = &recs[slot];
     emit_block(in + buf.in_off, syms + buf.sym_off + rec->sym_begin, rec, &plans[slot],
@@ -369,6 +440,8 @@ struct zsc_hip_deflate_plan {
     std::vector<SubBatch> subs;
     /* scratch shared by all sub-batches (sized for the largest) */
     DevBuf d_sorted, d_tmp_syms, d_rank, d_hib, d_dir, d_recs, d_plans, d_pout;
+    DevBuf d_seg_tok, d_seg_sidx; /* per long buffer: token staging of the segmented parser */
+    bool use_seg = true;
     DevBuf d_res; /* one ZdResult per buffer of the whole plan */
     uint64_t rank_base_off = 0;
     bool profile = false;
@@ -571,6 +644,19 @@ extern "C" ZlibReturn zsc_hip_deflate_plan_create(zsc_hip_deflate_plan **plan_ou
                              sb.d_order.bytes;
     }
 
+    pl->use_seg = getenv("ZSC_HIP_NO_SEG") == nullptr && kLevels[level].slow;
+    uint64_t max_seg = 0;
+    for (const SubBatch &sb : pl->subs)
+        max_seg = std::max<uint64_t>(max_seg, sb.c36);
+    if (pl->use_seg && max_seg) {
+        if (!pl->d_seg_tok.ensure(max_seg * SG_W * SG_TOKCAP * 4ull) ||
+            !pl->d_seg_sidx.ensure(max_seg * SG_W * SG_TRACE * 2ull)) {
+            zsc_hip_deflate_plan_destroy(pl);
+            return Z_MEM_ERROR;
+        }
+        pl->scratch_bytes += pl->d_seg_tok.bytes + pl->d_seg_sidx.bytes;
+    }
+
     /* shared scratch: sorted (4 B/position), tmp aliased with the symbol stream
      * (4 B/position, tmp is dead once the sort kernel ends), rank (2 B/position,
      * indexed by input offset), dir (2 B/position), block records + plans */
@@ -657,7 +743,14 @@ extern "C" ZlibReturn zsc_hip_deflate_plan_run(zsc_hip_deflate_plan *pl, const v
                        (const uint32_t *)sb.d_order.p, (const uint32_t *)sorted,                 \
                        (const uint16_t *)rank, (const uint16_t *)hib, tmp_syms, recs, pout, cfg, \
                        (uint32_t)(FIRST), (uint32_t)(COUNT))
-            ZSC_LAUNCH_PARSE(LzLds, 0, sb.c36);
+            if (pl->use_seg && sb.c36 > 0)
+                hipLaunchKernelGGL(k_parse_seg, dim3(sb.c36), dim3(SG_W * 64), 0, st, in, bufs,
+                                   (const uint32_t *)sb.d_order.p, (const uint32_t *)sorted,
+                                   (const uint16_t *)rank, (const uint16_t *)hib, tmp_syms, recs,
+                                   pout, (uint32_t *)pl->d_seg_tok.p, (uint16_t *)pl->d_seg_sidx.p,
+                                   cfg, 0u, sb.c36);
+            else
+                ZSC_LAUNCH_PARSE(LzLds, 0, sb.c36);
             ZSC_LAUNCH_PARSE(LzLds16k, sb.c36, sb.c16 - sb.c36);
             ZSC_LAUNCH_PARSE(LzLds8k, sb.c16, sb.c8 - sb.c16);
             ZSC_LAUNCH_PARSE(LzLds4k, sb.c8, sb.count - sb.c8);
@@ -755,6 +848,8 @@ extern "C" void zsc_hip_deflate_plan_destroy(zsc_hip_deflate_plan *pl)
     pl->d_tmp_syms.release();
     pl->d_rank.release();
     pl->d_hib.release();
+    pl->d_seg_tok.release();
+    pl->d_seg_sidx.release();
     pl->d_dir.release();
     pl->d_recs.release();
     pl->d_plans.release();
