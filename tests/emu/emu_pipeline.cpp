@@ -224,6 +224,7 @@ extern "C" int emu_compress(const uint8_t *src, uint32_t n, int level, int wrap,
     ZdBuf buf;
     memset(&buf, 0, sizeof buf);
     buf.in_len = n;
+    buf.max_blocks = max_blocks;
     buf.out_cap = out_cap;
     buf.level = (uint32_t)level;
     buf.wrap = (uint32_t)wrap;
