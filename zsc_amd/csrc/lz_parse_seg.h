@@ -175,6 +175,12 @@ DEV void sg_phase_parse(const LzJob &job, SgLds *lds, const SgScratch &scr, int 
     uint32_t *tok = scr.tok + (uint32_t)w * SG_TOKCAP;
     uint16_t *sidx = scr.sidx + (uint32_t)w * SG_TRACE;
     uint32_t ntok = 0, nstaged = 0, exit_kind = 0;
+    /* rank[] / hib[] of 64 consecutive positions, one per lane: a search reads them with
+     * v_readlane instead of a dependent global load */
+    LANEVAR(uint32_t, rkhb);
+    uint32_t rk_at = 0;
+    int rk_valid = 0;
+    FOR_LANES { LV(rkhb) = 0; }
 
     for (;;) {
         uint32_t look = st.data_end - p;
@@ -232,8 +238,18 @@ DEV void sg_phase_parse(const LzJob &job, SgLds *lds, const SgScratch &scr, int 
             sc.head_seen = 0;
             const uint32_t tile = p >> 15;
             const uint32_t *runA = job.sorted + (uint64_t)tile * ZD_TILE;
-            const int32_t hiA = (int32_t)UNI(job.rank[p]) - 1;
-            const int32_t hiB = tile ? (int32_t)(int16_t)UNI(job.hib[p]) : -1;
+            if (!rk_valid || p - rk_at >= WAVE) {
+                rk_valid = 1;
+                rk_at = p;
+                FOR_LANES
+                {
+                    const uint32_t x = p + (uint32_t)LANE;
+                    LV(rkhb) = x + 2 < job.n ? ((uint32_t)job.rank[x] | ((uint32_t)job.hib[x] << 16)) : 0u;
+                }
+            }
+            const uint32_t rh = READLANE(rkhb, p - rk_at);
+            const int32_t hiA = (int32_t)(rh & 0xffffu) - 1;
+            const int32_t hiB = tile ? (int32_t)(int16_t)(rh >> 16) : -1;
             int verdict = 0;
             LZ_WALK_RUN(runA, hiA + WAVE, tile << 15, LZ_MEMB_ALL, verdict);
             if (verdict == 1 && tile != 0) {
