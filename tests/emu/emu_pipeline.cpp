@@ -16,6 +16,24 @@ struct uint4 { uint32_t x, y, z, w; };
 
 #include "../../zsc_amd/csrc/hash_sort.h"
 #include "../../zsc_amd/csrc/lz_parse.h"
+/* event counters for tools/seg_stats.py: [0] batches, [1] long compares; per segment a
+ * record (segment | redo flag, batches) is appended to g_sg_log */
+extern "C" { unsigned long long g_sg_cnt[4]; unsigned g_sg_log[1 << 20]; unsigned g_sg_nlog; }
+static unsigned long long g_sg_mark;
+static inline void sg_count(int what, unsigned n)
+{
+    if (what < 2)
+        g_sg_cnt[what] += n;
+    else if (what == 2) {
+        g_sg_mark = g_sg_cnt[0];
+        if (g_sg_nlog + 2 <= (1u << 20))
+            g_sg_log[g_sg_nlog] = n;
+    } else if (g_sg_nlog + 2 <= (1u << 20)) {
+        g_sg_log[g_sg_nlog + 1] = (unsigned)(g_sg_cnt[0] - g_sg_mark);
+        g_sg_nlog += 2;
+    }
+}
+#define SG_COUNT(what, n) sg_count(what, n)
 #include "../../zsc_amd/csrc/lz_parse_seg.h"
 #include "../../zsc_amd/csrc/huff_plan.h"
 #include "../../zsc_amd/csrc/bit_emit.h"
@@ -32,6 +50,7 @@ struct EmuChains {
     uint32_t n, ntiles;
     std::vector<uint32_t> sorted, tmp;
     std::vector<uint16_t> rank, dir, hib;
+    std::vector<uint32_t> cnt;
 };
 
 static void build_chains(EmuChains &c, const uint8_t *src, uint32_t n)
@@ -45,6 +64,7 @@ static void build_chains(EmuChains &c, const uint8_t *src, uint32_t n)
     c.rank.assign((size_t)n + 64, 0xdead);
     c.dir.assign((size_t)c.ntiles * ZD_DIR_STRIDE, 0xdead);
     c.hib.assign((size_t)n + 64, 0xdead);
+    c.cnt.assign((size_t)n + 64, 0xdeaddead);
     uint32_t owners = n >= 3 ? n - 2 : 0; /* positions 0..n-3 own a 3-byte string */
     for (uint32_t t = 0; t < c.ntiles; t++) {
         HsTile tile;
@@ -55,54 +75,56 @@ static void build_chains(EmuChains &c, const uint8_t *src, uint32_t n)
         tile.sorted = c.sorted.data() + (size_t)t * ZD_TILE;
         tile.tmp = c.tmp.data() + (size_t)t * ZD_TILE;
         tile.rank = c.rank.data();
-        tile.dir = (t + 1 < c.ntiles) ? c.dir.data() + (size_t)t * ZD_DIR_STRIDE : nullptr;
+        tile.dir = c.dir.data() + (size_t)t * ZD_DIR_STRIDE;
         tile.dir_prev = nullptr;
         tile.hib = nullptr;
+        tile.cnt = nullptr;
         HsLds lds;
         for (int ph = 0; ph < HS_PHASES; ph++)
             for (int w = 0; w < HS_WAVES; w++)
                 hash_sort_phase(tile, &lds, w, ph);
     }
-    for (uint32_t t = 1; t < c.ntiles; t++) { /* kernel 1b */
+    for (uint32_t t = 0; t < c.ntiles; t++) { /* kernel 1b */
         HsTile tile;
         memset(&tile, 0, sizeof tile);
         tile.in = c.in.data();
         tile.n = n;
         tile.start = t * ZD_TILE;
         tile.m = owners > tile.start ? (owners - tile.start < ZD_TILE ? owners - tile.start : ZD_TILE) : 0;
-        tile.dir_prev = c.dir.data() + (size_t)(t - 1) * ZD_DIR_STRIDE;
+        tile.rank = c.rank.data();
+        tile.dir = c.dir.data() + (size_t)t * ZD_DIR_STRIDE;
+        tile.dir_prev = t ? c.dir.data() + (size_t)(t - 1) * ZD_DIR_STRIDE : nullptr;
         tile.hib = c.hib.data();
+        tile.cnt = c.cnt.data();
         for (int w = 0; w < HS_WAVES; w++)
             hs_link_prev(tile, w);
     }
 }
 
-int g_seg_mode = 0; /* 0: runtime's choice, 1: force wave-per-buffer, 2: segmented + successors parse first,
-                       3: segmented + predecessors first (no hand-over is ever found in time) */
+int g_seg_mode = 0; /* 0: runtime's choice, 1: force wave-per-buffer, 2: segmented, segments handed out last first,
+                       3: segmented, first first (a parser never finds its successors' traces) */
 extern "C" void emu_set_seg_mode(int m) { g_seg_mode = m; }
 
 static void run_parse_seg(const LzJob &job, int order)
 {
     SgLds *lds = (SgLds *)malloc(sizeof(SgLds));
     memset(lds, 0x6B, sizeof(SgLds));
-    std::vector<uint32_t> tok((size_t)SG_W * SG_TOKCAP, 0xDDDDDDDD);
-    std::vector<uint16_t> sidx((size_t)SG_W * SG_TRACE, 0xDDDD);
+    std::vector<uint32_t> tok((size_t)SG_NS * SG_TOKCAP, 0xDDDDDDDD);
+    std::vector<uint16_t> sidx((size_t)SG_NS * SG_TRACE, 0xDDDD);
     SgScratch scr = {tok.data(), sidx.data()};
     for (int w = 0; w < SG_W; w++)
         sg_init(lds, w);
+    lds->emu_ascending = order == 3;
     while (!lds->finished) {
         for (int w = 0; w < SG_W; w++)
             sg_phase_begin(job, lds, w);
+        /* waves run one after the other here, so the first one drains the queue */
         do {
-            if (order == 2)
-                for (int w = SG_W - 1; w >= 0; w--)
-                    sg_phase_parse(job, lds, scr, w);
-            else
-                for (int w = 0; w < SG_W; w++)
-                    sg_phase_parse(job, lds, scr, w);
+            for (int w = SG_W - 1; w >= 0; w--)
+                sg_phase_parse(job, lds, scr, w);
             for (int w = 0; w < SG_W; w++)
                 sg_phase_resolve(job, lds, scr, w);
-        } while (lds->again);
+        } while (lds->redo);
     }
     free(lds);
 }
@@ -169,6 +191,7 @@ extern "C" int emu_parse(const uint8_t *src, uint32_t n, int level, int strategy
     job.sorted = c.sorted.data();
     job.rank = c.rank.data();
     job.hib = c.hib.data();
+    job.cnt = c.cnt.data();
     job.syms = syms;
     job.blocks = blocks;
     job.out = &out;
@@ -214,6 +237,7 @@ extern "C" int emu_compress(const uint8_t *src, uint32_t n, int level, int wrap,
     job.sorted = c.sorted.data();
     job.rank = c.rank.data();
     job.hib = c.hib.data();
+    job.cnt = c.cnt.data();
     job.syms = syms.data();
     job.blocks = recs.data();
     job.out = &po;

@@ -47,9 +47,11 @@ typedef struct {
     uint32_t *sorted;   /* TILE entries */
     uint32_t *tmp;      /* TILE entries */
     uint16_t *rank;     /* per position of the buffer */
-    uint16_t *dir;      /* DIR_STRIDE entries, or null when no later tile will look back */
+    uint16_t *dir;      /* DIR_STRIDE entries: first sorted index of every bucket */
     const uint16_t *dir_prev; /* directory of the previous tile of the same buffer, or null */
     uint16_t *hib;      /* per position of the buffer: last sorted index of its bucket in the previous tile */
+    uint32_t *cnt;      /* per position of the buffer: earlier members of its bucket in its own tile (low
+                           half) and members of the bucket in the previous tile (high half) */
 } HsTile;
 
 /* UPDATE_HASH over three bytes, reference src/deflate.c:174-175 */
@@ -208,20 +210,25 @@ DEV void hs_directory(const HsTile &t, int w)
 }
 
 /* kernel 1b (after every tile of the batch has its directory): for each position of
- * this tile, where its hash bucket ends in the PREVIOUS tile's sorted array.  With
- * rank[] this makes both halves of a position's chain addressable from two
- * sequentially readable arrays -- the parser never does a dependent table lookup. */
+ * this tile, how long its chain is inside the tile, and where its hash bucket lies in
+ * the PREVIOUS tile's sorted array.  With rank[] this makes a position's whole chain
+ * addressable up front -- the parser never does a dependent table lookup and never
+ * has to look at an entry to find the end of a bucket. */
 DEV void hs_link_prev(const HsTile &t, int w)
 {
-    if (!t.dir_prev)
-        return;
     for (uint32_t s = (uint32_t)w * WAVE; s < t.m; s += HS_WAVES * WAVE) {
         FOR_LANES
         {
             uint32_t i = s + (uint32_t)LANE;
             if (i < t.m) {
                 uint32_t h = hs_hash3(t.in, t.start + i, t.n);
-                t.hib[t.start + i] = (uint16_t)(t.dir_prev[h + 1] - 1u); /* 0xffff: bucket empty from the start */
+                uint32_t c = (uint32_t)t.rank[t.start + i] - (uint32_t)t.dir[h];
+                if (t.dir_prev) {
+                    const uint32_t lo = t.dir_prev[h], end = t.dir_prev[h + 1];
+                    t.hib[t.start + i] = (uint16_t)(end - 1u); /* 0xffff: bucket empty from the start */
+                    c |= (end - lo) << 16;
+                }
+                t.cnt[t.start + i] = c;
             }
         }
     }
@@ -261,8 +268,7 @@ DEV void hash_sort_phase(const HsTile &t, HsLds *lds, int w, int phase)
         hs_scatter(t, lds, w, 1);
         break;
     case 7:
-        if (t.dir)
-            hs_directory(t, w);
+        hs_directory(t, w);
         break;
     }
 }

@@ -66,6 +66,7 @@ typedef struct {
     const uint32_t *sorted; /* tile 0 of this buffer; tile t at + t*ZD_TILE */
     const uint16_t *rank;   /* this buffer: index of a position in its tile's sorted array */
     const uint16_t *hib;    /* this buffer: last index of the position's bucket in the previous tile */
+    const uint32_t *cnt;    /* this buffer: chain lengths in the own | previous tile (hash_sort.h) */
     uint32_t *syms;         /* this buffer's symbol slots */
     ZdBlockRec *blocks;     /* this buffer's block records */
     ZdParseOut *out;

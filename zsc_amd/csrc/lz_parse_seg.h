@@ -35,12 +35,17 @@
 
 #include "lz_parse.h"
 
-#define SG_W 8                      /* waves per workgroup = segments per super-step */
-#define SG_G 1024u                  /* positions per segment */
-#define SG_OV 512u                  /* how far past its segment a wave looks for a hand-over */
-#define SG_SPAN (SG_W * SG_G)
-#define SG_TRACE (SG_G + SG_OV)     /* positions a wave records */
-#define SG_TOKCAP (SG_G + SG_OV + 320u) /* tokens one wave can emit in one round */
+#ifndef SG_COUNT
+#define SG_COUNT(what, n) /* event counters of the host emulation (tests/emu) */
+#endif
+
+#define SG_W 8                      /* waves per workgroup */
+#define SG_G 256u                   /* positions per segment */
+#define SG_SPAN 8192u               /* positions per super-step */
+#define SG_NS (SG_SPAN / SG_G)      /* segments per super-step, handed to the waves by a work queue */
+#define SG_OV 512u                  /* how far past its segment a parser looks for a hand-over */
+#define SG_TRACE SG_G               /* positions a segment records (its own) */
+#define SG_TOKCAP (SG_G + SG_OV + 320u) /* tokens one segment's parser can emit */
 
 #define SG_EXIT_SYNCED 1u
 #define SG_EXIT_UNSYNCED 2u
@@ -48,23 +53,24 @@
 #define SG_EXIT_END 4u
 
 typedef struct {
-    uint32_t run;                                   /* parse in the coming round */
     uint32_t start_p, start_len, start_at, start_pending;
     uint32_t exit_kind, exit_p, exit_len, exit_at, exit_pending;
-    uint32_t ntok;                                  /* tokens emitted in its last round */
-    uint32_t first_tok;                             /* first token that belongs to the serial parse */
+    uint32_t ntok;                                  /* tokens its parser emitted */
 } SgWave;
 
 struct SgLds {
     static constexpr uint32_t RING = 45056u, CHUNK = 2048u;
     static constexpr bool HAS_INS = false;
     uint8_t ring[RING + 512];
-    uint32_t stage[SG_W][WAVE];
-    uint32_t trace[SG_W][SG_TRACE / 32];
-    SgWave wv[SG_W];
+    uint32_t trace[SG_NS][SG_TRACE / 32];
+    SgWave wv[SG_NS];             /* one record per segment of the super-step */
     /* workgroup state */
     uint32_t S0;                  /* first position of the current super-step */
-    uint32_t again, finished, chain;
+    uint32_t finished;
+    uint32_t queue;               /* segments not handed out yet (taken from the top) */
+    uint32_t redo, redo_seg, redo_from; /* a segment to parse again from segment redo_from's exit state */
+    uint32_t chain, chain_ft;     /* where the resolver stands: segment and first valid token */
+    uint32_t emu_ascending;       /* test hook of the host emulation: hand segments out bottom-up */
     uint32_t lo, hi, wrap_base;   /* window ring */
     /* the buffer's symbol stream being assembled */
     uint32_t nsyms, nblocks, blk_sym0, blk_in0, cov;
@@ -73,8 +79,8 @@ struct SgLds {
 
 /* scratch in HBM per workgroup */
 typedef struct {
-    uint32_t *tok;  /* SG_W * SG_TOKCAP tokens */
-    uint16_t *sidx; /* SG_W * SG_TRACE: tokens emitted before a fresh position */
+    uint32_t *tok;  /* SG_NS * SG_TOKCAP tokens */
+    uint16_t *sidx; /* SG_NS * SG_TRACE: tokens emitted before a fresh position */
 } SgScratch;
 
 /* the window base the serial parse has at a loop top at position p: every slide of
@@ -92,17 +98,16 @@ DEV uint32_t sg_base(uint32_t p, uint32_t n)
     }
 }
 
-DEV void sg_flush_stage(uint32_t *tok, SgLds *lds, int w, uint32_t ntok, uint32_t nstaged)
+/* number of segments of the super-step that starts at S0 */
+DEV uint32_t sg_nact(uint32_t S0, uint32_t n)
 {
-    const uint32_t first = ntok - nstaged;
-    FOR_LANES
-    {
-        if ((uint32_t)LANE < nstaged)
-            tok[first + (uint32_t)LANE] = lds->stage[w][LANE];
-    }
+    const uint32_t left = n - S0;
+    if (left == 0)
+        return 1; /* the empty buffer: segment 0 still reports the end of the input */
+    return left >= SG_SPAN ? SG_NS : (left + SG_G - 1) / SG_G;
 }
 
-/* phase 1 (wave 0): slide the window to the new super-step, decide who parses */
+/* phase 1 (wave 0): slide the window to the new super-step, fill the work queue */
 DEV void sg_phase_begin(const LzJob &job, SgLds *lds, int w)
 {
     if (w != 0)
@@ -122,35 +127,194 @@ DEV void sg_phase_begin(const LzJob &job, SgLds *lds, int w)
         lds->lo = st.lo;
         lds->hi = st.hi;
         lds->wrap_base = st.wrap_base;
-        for (int k = 1; k < SG_W; k++) {
-            const uint32_t a = S0 + (uint32_t)k * SG_G;
-            lds->wv[k].run = a < job.n ? 1u : 0u;
-            lds->wv[k].start_p = a;
-            lds->wv[k].start_len = 2;
-            lds->wv[k].start_at = 0;
-            lds->wv[k].start_pending = 0;
-            lds->wv[k].first_tok = 0;
-            lds->wv[k].ntok = 0;
-        }
-        lds->wv[0].run = 1; /* its start state was carried over */
-        lds->wv[0].first_tok = 0;
+        lds->queue = sg_nact(S0, job.n);
+        lds->redo = 0;
         lds->chain = 0;
-        lds->again = 0;
+        lds->chain_ft = 0;
     }
     FOR_LANES
     {
-        for (uint32_t i = (uint32_t)LANE; i < SG_W * (SG_TRACE / 32); i += WAVE)
+        for (uint32_t i = (uint32_t)LANE; i < SG_NS * (SG_TRACE / 32); i += WAVE)
             (&lds->trace[0][0])[i] = 0;
     }
     WAVE_SYNC();
 }
 
-/* phase 2 (every wave that has `run` set): parse one segment */
-DEV void sg_phase_parse(const LzJob &job, SgLds *lds, const SgScratch &scr, int w)
+/* ---- the search ------------------------------------------------------------------
+ *
+ * longest_match (src/deflate.c:1414-1521) for one position, by the whole wave.  The
+ * chain of p is the run of its hash bucket below rank[p] in its own tile's sorted
+ * array, continued by the bucket's run in the previous tile; cnt[p] holds both run
+ * lengths, so candidate number v (0 = newest) has a known address and 64 of them are
+ * one coalesced load.  Per candidate the wave does what the reference's pre-check does
+ * (:1462-1469): two window reads and two compares.  The four bytes read at the
+ * candidate also tell whether it can be longer than three bytes at all; only those
+ * that can get the cooperative 256-byte compare.  Candidates that pass the pre-check
+ * but cannot improve on best_len only cost chain budget, which is settled for all of
+ * them at once with a popcount. */
+
+/* two consecutive dwords of the 256-byte register copy of the window at pw_at */
+#define SG_PEEK32(pos, out)                                                                   \
+    do {                                                                                      \
+        const uint32_t _k = (pos)-pw_at;                                                      \
+        if (_k <= 248u) {                                                                     \
+            const uint32_t _lo = READLANE(pw, _k >> 2), _hi = READLANE(pw, (_k >> 2) + 1u);   \
+            (out) = (uint32_t)((((uint64_t)_hi << 32) | _lo) >> ((_k & 3u) * 8u));            \
+        } else {                                                                              \
+            (out) = UNI(ld_u32(&lds->ring[lz_ridx<L>(st, (pos))]));                           \
+        }                                                                                     \
+    } while (0)
+
+#define SG_LOAD(E, B)                                                                         \
+    FOR_LANES                                                                                 \
+    {                                                                                         \
+        const uint32_t _v = (B)*64u + (uint32_t)LANE;                                         \
+        uint32_t _e = ZD_ENTRY_NONE;                                                          \
+        if (_v < total) {                                                                     \
+            const int32_t _i = _v < nA ? hiA - (int32_t)_v                                    \
+                                       : hiB - (int32_t)(_v - nA) - (int32_t)ZD_TILE;         \
+            _e = runA[_i];                                                                    \
+        }                                                                                     \
+        LV(E) = _e;                                                                           \
+    }
+
+/* evaluate candidates 64*B .. 64*B+63 (entries E); sets fin when the search is over */
+#define SG_EVAL(E, B)                                                                         \
+    do {                                                                                      \
+        LANEVAR(uint32_t, _q);                                                                \
+        LANEVAR(uint32_t, _w0);                                                               \
+        LANEVAR(int, _alive);                                                                 \
+        LANEVAR(int, _pass);                                                                  \
+        LANEVAR(int, _maybe);                                                                 \
+        FOR_LANES                                                                             \
+        {                                                                                     \
+            const uint32_t _v = (B)*64u + (uint32_t)LANE;                                     \
+            const uint32_t q = tileA + (LV(E) & ZD_TILE_MASK) - (_v < nA ? 0u : ZD_TILE);     \
+            LV(_q) = q;                                                                       \
+            /* the chain head may lie at exactly MAX_DIST (:2032), later links may not (:1519) */ \
+            LV(_alive) = _v < total &&                                                        \
+                         (_v == 0 ? (q > st.base && p - q <= ZD_MAX_DIST) : q > floor_pos);   \
+        }                                                                                     \
+        const uint64_t _m_alive = BALLOT(_alive);                                             \
+        if ((B) == 0) {                                                                       \
+            if (!(_m_alive & 1ull)) {                                                         \
+                fin = 2; /* no chain head in the window: longest_match is not called */       \
+                break;                                                                        \
+            }                                                                                 \
+            head_seen = 1;                                                                    \
+            if (best >= look) {                                                               \
+                fin = 1;                                                                      \
+                break;                                                                        \
+            }                                                                                 \
+            SG_PEEK32(p + best - 1, sb);                                                      \
+            sb &= 0xffffu;                                                                    \
+        }                                                                                     \
+        SG_COUNT(0, 1);                                                                       \
+        FOR_LANES                                                                             \
+        {                                                                                     \
+            uint32_t w0 = 0;                                                                  \
+            int c = 0;                                                                        \
+            if (LV(_alive)) {                                                                 \
+                w0 = ld_u32(&lds->ring[lz_ridx<L>(st, LV(_q))]);                              \
+                c = ld_u16(&lds->ring[lz_ridx<L>(st, LV(_q) + best - 1)]) == sb &&            \
+                    (w0 & 0xffffu) == (s0123 & 0xffffu);                                      \
+            }                                                                                 \
+            LV(_w0) = w0;                                                                     \
+            LV(_pass) = c;                                                                    \
+            LV(_maybe) = LV(_alive) && w0 == s0123;                                           \
+        }                                                                                     \
+        uint64_t _todo = BALLOT(_pass);                                                       \
+        const uint64_t _m_maybe = cap > 3u ? BALLOT(_maybe) : 0ull;                           \
+        while (_todo != 0) {                                                                  \
+            /* passers that can beat best_len: any at all while best_len is 2, later only     \
+             * those whose first four bytes match */                                          \
+            const uint64_t _cand = best >= 3u ? (_todo & _m_maybe) : _todo;                   \
+            const int _j = _cand ? CTZ64(_cand) : 64;                                         \
+            const uint64_t _below = _j < 64 ? (_todo & ((1ull << _j) - 1ull)) : _todo;        \
+            const uint32_t _nb = (uint32_t)POPC64(_below);                                    \
+            if (_nb >= budget) {                                                              \
+                fin = 1; /* the chain budget ends on a candidate that changes nothing */      \
+                break;                                                                        \
+            }                                                                                 \
+            budget -= _nb;                                                                    \
+            if (_j == 64)                                                                     \
+                break;                                                                        \
+            const uint32_t _qj = READLANE(_q, _j);                                            \
+            uint32_t _len = 3;                                                                \
+            if ((_m_maybe >> _j) & 1ull) {                                                    \
+                SG_COUNT(1, 1);                                                               \
+                if (pv_at != p) {                                                             \
+                    pv_at = p;                                                                \
+                    FOR_LANES { LV(pv) = ld_u32(&lds->ring[lz_ridx<L>(st, p + 4u * (uint32_t)LANE)]); } \
+                }                                                                             \
+                LANEVAR(uint32_t, _diff);                                                     \
+                LANEVAR(int, _differs);                                                       \
+                FOR_LANES                                                                     \
+                {                                                                             \
+                    LV(_diff) = ld_u32(&lds->ring[lz_ridx<L>(st, _qj + 4u * (uint32_t)LANE)]) ^ LV(pv); \
+                    LV(_differs) = LV(_diff) != 0;                                            \
+                }                                                                             \
+                const uint64_t _dm = BALLOT(_differs);                                        \
+                if (_dm != 0) {                                                               \
+                    const int _f = CTZ64(_dm);                                                \
+                    _len = 4u * (uint32_t)_f + ((uint32_t)CTZ32(READLANE(_diff, _f)) >> 3);   \
+                } else {                                                                      \
+                    _len = 256;                                                               \
+                    if (cap > 256 && UNI(lds->ring[lz_ridx<L>(st, _qj + 256)]) ==             \
+                                         UNI(lds->ring[lz_ridx<L>(st, p + 256)])) {           \
+                        _len = 257;                                                           \
+                        if (cap > 257 && UNI(lds->ring[lz_ridx<L>(st, _qj + 257)]) ==         \
+                                             UNI(lds->ring[lz_ridx<L>(st, p + 257)]))         \
+                            _len = 258;                                                       \
+                    }                                                                         \
+                }                                                                             \
+                if (_len > cap)                                                               \
+                    _len = cap;                                                               \
+            }                                                                                 \
+            int _improved = 0;                                                                \
+            if (_len > best) {                                                                \
+                where = _qj;                                                                  \
+                best = _len;                                                                  \
+                _improved = 1;                                                                \
+                if (_len >= nice) {                                                           \
+                    fin = 1;                                                                  \
+                    break;                                                                    \
+                }                                                                             \
+            }                                                                                 \
+            if (--budget == 0) {                                                              \
+                fin = 1;                                                                      \
+                break;                                                                        \
+            }                                                                                 \
+            if (_improved) {                                                                  \
+                SG_PEEK32(p + best - 1, sb);                                                  \
+                sb &= 0xffffu;                                                                \
+                FOR_LANES                                                                     \
+                {                                                                             \
+                    int c = 0;                                                                \
+                    if (LV(_alive) && LANE > _j && (LV(_w0) & 0xffffu) == (s0123 & 0xffffu))  \
+                        c = ld_u16(&lds->ring[lz_ridx<L>(st, LV(_q) + best - 1)]) == sb;      \
+                    LV(_pass) = c;                                                            \
+                }                                                                             \
+                _todo = BALLOT(_pass);                                                        \
+            } else {                                                                          \
+                _todo &= ~((2ull << _j) - 1ull);                                              \
+            }                                                                                 \
+        }                                                                                     \
+        if (!fin) {                                                                           \
+            const uint32_t _left = total - (B)*64u;                                           \
+            const uint64_t _valid = _left >= 64u ? ~0ull : ((1ull << _left) - 1ull);          \
+            if (_m_alive != _valid)                                                           \
+                fin = 1; /* the chain leaves the window (:1519) */                            \
+        }                                                                                     \
+    } while (0)
+
+/* parse from (p, cur_len, cur_at, pending) -- a state of the serial parse, or the fresh
+ * state at the start of segment s -- until the parse can be handed to a later segment's
+ * tokens, gives up, or leaves the super-step */
+DEV void sg_parse_segment(const LzJob &job, SgLds *lds, const SgScratch &scr, uint32_t s,
+                          uint32_t p, uint32_t cur_len, uint32_t cur_at, int pending)
 {
     typedef SgLds L;
-    if (!UNI(lds->wv[w].run))
-        return;
     LzState st;
     st.lo = UNI(lds->lo);
     st.hi = UNI(lds->hi);
@@ -160,27 +324,35 @@ DEV void sg_phase_parse(const LzJob &job, SgLds *lds, const SgScratch &scr, int 
     const uint32_t S0 = UNI(lds->S0);
     const uint64_t E64 = (uint64_t)S0 + SG_SPAN;
     const uint32_t E = E64 < job.n ? (uint32_t)E64 : job.n; /* end of the super-step */
-    const uint32_t a_w = S0 + (uint32_t)w * SG_G;
-    const uint32_t e_w = a_w + SG_G < E ? a_w + SG_G : E;
-    const int last_seg = e_w == E;
+    const uint32_t a_s = S0 + s * SG_G;
+    const uint32_t e_s = a_s + SG_G < E ? a_s + SG_G : E;
 
-    uint32_t p = UNI(lds->wv[w].start_p);
-    uint32_t cur_len = UNI(lds->wv[w].start_len), cur_at = UNI(lds->wv[w].start_at);
-    int pending = (int)UNI(lds->wv[w].start_pending);
     st.base = sg_base(p, job.n);
     {
         uint64_t end = (uint64_t)st.base + 2ull * ZD_TILE;
         st.data_end = end < job.n ? (uint32_t)end : job.n;
     }
-    uint32_t *tok = scr.tok + (uint32_t)w * SG_TOKCAP;
-    uint16_t *sidx = scr.sidx + (uint32_t)w * SG_TRACE;
+    uint32_t *tok = scr.tok + s * SG_TOKCAP;
+    uint16_t *sidx = scr.sidx + s * SG_TRACE;
     uint32_t ntok = 0, nstaged = 0, exit_kind = 0;
-    /* rank[] / hib[] of 64 consecutive positions, one per lane: a search reads them with
-     * v_readlane instead of a dependent global load */
-    LANEVAR(uint32_t, rkhb);
-    uint32_t rk_at = 0;
-    int rk_valid = 0;
-    FOR_LANES { LV(rkhb) = 0; }
+
+    /* everything a search needs from memory that does not depend on the candidates is
+     * kept in registers, one value per lane, and read with v_readlane:
+     *   mrk/mcn  rank|hib and cnt of 64 consecutive positions
+     *   pw       256 bytes of the window around p
+     *   pv       the string at p as the long compare wants it (dword l = bytes 4l..4l+3)
+     *   stg      tokens not yet written out;  sdx  token counts at fresh positions */
+    LANEVAR(uint32_t, mrk);
+    LANEVAR(uint32_t, mcn);
+    LANEVAR(uint32_t, pw);
+    LANEVAR(uint32_t, pv);
+    LANEVAR(uint32_t, stg);
+    LANEVAR(uint32_t, sdx);
+    FOR_LANES { LV(mrk) = LV(mcn) = LV(pw) = LV(pv) = LV(stg) = LV(sdx) = 0; }
+    uint32_t mt_at = 0, pw_at = 0, pv_at = 0xffffffffu;
+    int mt_valid = 0, pw_valid = 0;
+    uint32_t tw = 0, tw_idx = 0xffffffffu; /* trace word being filled */
+    uint32_t sd_blk = 0xffffffffu;         /* 64-position block sdx belongs to */
 
     for (;;) {
         uint32_t look = st.data_end - p;
@@ -193,75 +365,125 @@ DEV void sg_phase_parse(const LzJob &job, SgLds *lds, const SgScratch &scr, int 
             }
         }
         const int fresh = !pending && cur_len == 2;
-        if (p >= e_w) {
-            if (last_seg) {
+        if (p >= e_s) {
+            if (p >= E) {
                 exit_kind = SG_EXIT_LAST;
                 break;
             }
-            if (fresh && p - (a_w + SG_G) < SG_TRACE) {
-                const uint32_t r = p - (a_w + SG_G); /* index in the successor's trace */
-                if ((UNI(lds->trace[w + 1][r >> 5]) >> (r & 31u)) & 1u) {
+            if (fresh) {
+                /* the segment p lies in recorded the positions its own parser was fresh at */
+                const uint32_t t = (p - S0) / SG_G, r = (p - S0) % SG_G;
+                if ((UNI(lds->trace[t][r >> 5]) >> (r & 31u)) & 1u) {
                     exit_kind = SG_EXIT_SYNCED;
                     break;
                 }
             }
-            if (p >= e_w + SG_OV) {
+            if (p >= e_s + SG_OV) {
                 exit_kind = SG_EXIT_UNSYNCED;
                 break;
             }
-        }
-        if (fresh && p >= a_w && p - a_w < SG_TRACE) {
-            const uint32_t r = p - a_w;
-            ON_LANE0
-            {
-                sidx[r] = (uint16_t)ntok;
-                lds->trace[w][r >> 5] |= 1u << (r & 31u);
+        } else if (fresh && p >= a_s) {
+            const uint32_t r = p - a_s;
+            if ((r >> 5) != tw_idx) {
+                if (tw_idx != 0xffffffffu) {
+                    ON_LANE0 { lds->trace[s][tw_idx] = tw; }
+                }
+                tw_idx = r >> 5;
+                tw = 0;
             }
-            WAVE_SYNC();
+            tw |= 1u << (r & 31u);
+            if ((r >> 6) != sd_blk) {
+                if (sd_blk != 0xffffffffu) {
+                    FOR_LANES { sidx[sd_blk * 64u + (uint32_t)LANE] = (uint16_t)LV(sdx); }
+                }
+                sd_blk = r >> 6;
+            }
+            FOR_LANES
+            {
+                if ((uint32_t)LANE == (r & 63u))
+                    LV(sdx) = ntok;
+            }
+        }
+        if (!pw_valid || p < pw_at + 1u || p - pw_at > 224u) {
+            pw_valid = 1;
+            pw_at = p & ~3u;
+            if (pw_at >= 4u)
+                pw_at -= 4u;
+            FOR_LANES { LV(pw) = ld_u32(&lds->ring[lz_ridx<L>(st, pw_at + 4u * (uint32_t)LANE)]); }
         }
 
         const uint32_t prev_len = cur_len, prev_at = cur_at;
         cur_len = 2;
         if (look >= 3 && prev_len < job.cfg.lazy) {
-            LzSearch sc;
-            sc.p = p;
-            const uint32_t w0 = UNI(ld_u32(&lds->ring[lz_ridx<L>(st, p)]));
-            sc.h = (((w0 & 0xff) << 10) ^ (((w0 >> 8) & 0xff) << 5) ^ ((w0 >> 16) & 0xff)) & ZD_HASH_MASK;
-            sc.s01 = w0 & 0xffff;
-            sc.sb = 0;
-            sc.look = look;
-            sc.cap = look < 258u ? look : 258u;
-            sc.nice = job.cfg.nice < look ? job.cfg.nice : look;
-            sc.best = prev_len;
-            sc.budget = prev_len >= job.cfg.good ? job.cfg.chain >> 2 : job.cfg.chain;
-            sc.where = cur_at;
-            sc.head_seen = 0;
-            const uint32_t tile = p >> 15;
-            const uint32_t *runA = job.sorted + (uint64_t)tile * ZD_TILE;
-            if (!rk_valid || p - rk_at >= WAVE) {
-                rk_valid = 1;
-                rk_at = p;
+            if (!mt_valid || p - mt_at >= WAVE) {
+                mt_valid = 1;
+                mt_at = p;
                 FOR_LANES
                 {
                     const uint32_t x = p + (uint32_t)LANE;
-                    LV(rkhb) = x + 2 < job.n ? ((uint32_t)job.rank[x] | ((uint32_t)job.hib[x] << 16)) : 0u;
+                    const int ok = x + 2 < job.n;
+                    LV(mrk) = ok ? ((uint32_t)job.rank[x] | ((uint32_t)job.hib[x] << 16)) : 0u;
+                    LV(mcn) = ok ? job.cnt[x] : 0u;
                 }
             }
-            const uint32_t rh = READLANE(rkhb, p - rk_at);
-            const int32_t hiA = (int32_t)(rh & 0xffffu) - 1;
-            const int32_t hiB = tile ? (int32_t)(int16_t)(rh >> 16) : -1;
-            int verdict = 0;
-            LZ_WALK_RUN(runA, hiA + WAVE, tile << 15, LZ_MEMB_ALL, verdict);
-            if (verdict == 1 && tile != 0) {
-                verdict = 0;
-                LZ_WALK_RUN(runA - ZD_TILE, hiB + WAVE, (tile - 1) << 15, LZ_MEMB_ALL, verdict);
-            }
-            if (verdict != 3 && sc.head_seen) {
-                cur_at = sc.where;
-                cur_len = sc.best < look ? sc.best : look;
-                if (cur_len <= 5 &&
-                    (job.strategy == 1 || (cur_len == 3 && p - cur_at > ZD_TOO_FAR)))
-                    cur_len = 2;
+            const uint32_t rh = READLANE(mrk, p - mt_at), cn = READLANE(mcn, p - mt_at);
+            const uint32_t nA = cn & 0xffffu, total = nA + (cn >> 16);
+            if (total != 0) {
+                const int32_t hiA = (int32_t)(rh & 0xffffu) - 1, hiB = (int32_t)(rh >> 16);
+                const uint32_t tileA = p & ~ZD_TILE_MASK;
+                const uint32_t *runA = job.sorted + (uint64_t)(p >> 15) * ZD_TILE;
+                const uint32_t floor_pos = p - st.base > ZD_MAX_DIST ? p - ZD_MAX_DIST : st.base;
+                const uint32_t cap = look < 258u ? look : 258u;
+                const uint32_t nice = job.cfg.nice < look ? job.cfg.nice : look;
+                uint32_t best = prev_len, where = cur_at, sb = 0, s0123;
+                uint32_t budget = prev_len >= job.cfg.good ? job.cfg.chain >> 2 : job.cfg.chain;
+                int fin = 0, head_seen = 0;
+                SG_PEEK32(p, s0123);
+                LANEVAR(uint32_t, e0);
+                LANEVAR(uint32_t, e1);
+                LANEVAR(uint32_t, e2);
+                LANEVAR(uint32_t, e3);
+                LANEVAR(uint32_t, f0);
+                LANEVAR(uint32_t, f1);
+                LANEVAR(uint32_t, f2);
+                LANEVAR(uint32_t, f3);
+                SG_LOAD(e0, 0u);
+                SG_LOAD(e1, 1u);
+                SG_LOAD(e2, 2u);
+                SG_LOAD(e3, 3u);
+                for (uint32_t b0 = 0;; b0 += 4u) {
+                    const int more = (b0 + 4u) * 64u < total;
+                    if (more) {
+                        /* the next 256 candidates are on their way while these are looked at */
+                        SG_LOAD(f0, b0 + 4u);
+                        SG_LOAD(f1, b0 + 5u);
+                        SG_LOAD(f2, b0 + 6u);
+                        SG_LOAD(f3, b0 + 7u);
+                    }
+                    SG_EVAL(e0, b0);
+                    if (!fin && (b0 + 1u) * 64u < total)
+                        SG_EVAL(e1, b0 + 1u);
+                    if (!fin && (b0 + 2u) * 64u < total)
+                        SG_EVAL(e2, b0 + 2u);
+                    if (!fin && (b0 + 3u) * 64u < total)
+                        SG_EVAL(e3, b0 + 3u);
+                    if (fin || !more)
+                        break;
+                    FOR_LANES
+                    {
+                        LV(e0) = LV(f0);
+                        LV(e1) = LV(f1);
+                        LV(e2) = LV(f2);
+                        LV(e3) = LV(f3);
+                    }
+                }
+                if (fin != 2 && head_seen) {
+                    cur_at = where;
+                    cur_len = best < look ? best : look;
+                    if (cur_len <= 5 &&
+                        (job.strategy == 1 || (cur_len == 3 && p - cur_at > ZD_TOO_FAR)))
+                        cur_len = 2;
+                }
             }
         }
         uint32_t sym = 0;
@@ -273,7 +495,8 @@ DEV void sg_phase_parse(const LzJob &job, SgLds *lds, const SgScratch &scr, int 
             cur_len = 2;
             p += prev_len - 1;
         } else if (pending) {
-            sym = UNI(lds->ring[lz_ridx<L>(st, p - 1)]);
+            SG_PEEK32(p - 1, sym);
+            sym &= 0xffu;
             emit = 1;
             p++;
         } else {
@@ -281,30 +504,89 @@ DEV void sg_phase_parse(const LzJob &job, SgLds *lds, const SgScratch &scr, int 
             p++;
         }
         if (emit) {
-            ON_LANE0 { lds->stage[w][nstaged] = sym; }
-            WAVE_SYNC();
+            FOR_LANES
+            {
+                if ((uint32_t)LANE == nstaged)
+                    LV(stg) = sym;
+            }
             nstaged++;
             ntok++;
             if (nstaged == WAVE) {
-                sg_flush_stage(tok, lds, w, ntok, nstaged);
+                FOR_LANES { tok[ntok - WAVE + (uint32_t)LANE] = LV(stg); }
                 nstaged = 0;
             }
         }
     }
-    if (nstaged)
-        sg_flush_stage(tok, lds, w, ntok, nstaged);
+    FOR_LANES
+    {
+        if ((uint32_t)LANE < nstaged)
+            tok[ntok - nstaged + (uint32_t)LANE] = LV(stg);
+    }
+    if (sd_blk != 0xffffffffu) {
+        FOR_LANES { sidx[sd_blk * 64u + (uint32_t)LANE] = (uint16_t)LV(sdx); }
+    }
     ON_LANE0
     {
-        SgWave *me = &lds->wv[w];
+        if (tw_idx != 0xffffffffu)
+            lds->trace[s][tw_idx] = tw;
+        SgWave *me = &lds->wv[s];
         me->exit_kind = exit_kind;
         me->exit_p = p;
         me->exit_len = cur_len;
         me->exit_at = cur_at;
         me->exit_pending = (uint32_t)pending;
         me->ntok = ntok;
-        me->run = 0;
     }
     WAVE_SYNC();
+}
+
+/* phase 2 (every wave): take segments off the queue, last segment first -- by the time
+ * a segment's parser runs past its end, the segments behind it have usually been
+ * parsed, so it finds a hand-over.  Segment 0 starts from the state the previous
+ * super-step ended in, every other one fresh.  In a redo round (phase 3 found a parser
+ * that gave up) wave 0 parses on from that parser's exact state. */
+DEV void sg_phase_parse(const LzJob &job, SgLds *lds, const SgScratch &scr, int w)
+{
+    const uint32_t S0 = UNI(lds->S0);
+    const uint32_t nact = sg_nact(S0, job.n);
+    const int redo = (int)UNI(lds->redo);
+    if (redo && w != 0)
+        return;
+    for (int round = 0;; round++) {
+        uint32_t s, sp, slen = 2, sat = 0, spend = 0;
+        if (redo) {
+            if (round)
+                break;
+            const uint32_t k = UNI(lds->redo_from);
+            s = UNI(lds->redo_seg);
+            sp = UNI(lds->wv[k].exit_p);
+            slen = UNI(lds->wv[k].exit_len);
+            sat = UNI(lds->wv[k].exit_at);
+            spend = UNI(lds->wv[k].exit_pending);
+        } else {
+            LANEVAR(uint32_t, got);
+            FOR_LANES
+            {
+                LV(got) = 0;
+                if (LANE == 0)
+                    LV(got) = LDS_FETCH_ADD_U32(&lds->queue, 0xffffffffu);
+            }
+            const uint32_t old = READLANE(got, 0);
+            if (old == 0 || old > nact) /* empty (the counter may have gone below zero) */
+                break;
+            s = UNI(lds->emu_ascending) ? nact - old : old - 1;
+            sp = S0 + s * SG_G;
+            if (s == 0) {
+                sp = UNI(lds->wv[0].start_p);
+                slen = UNI(lds->wv[0].start_len);
+                sat = UNI(lds->wv[0].start_at);
+                spend = UNI(lds->wv[0].start_pending);
+            }
+        }
+        SG_COUNT(2, redo ? 0x10000 + s : s);
+        sg_parse_segment(job, lds, scr, s, sp, slen, sat, (int)spend);
+        SG_COUNT(3, 0);
+    }
 }
 
 /* append tokens [from, to) of one wave's round to the buffer's symbol stream,
@@ -370,38 +652,33 @@ DEV void sg_append(const LzJob &job, SgLds *lds, const uint32_t *tok, uint32_t f
     WAVE_SYNC();
 }
 
-/* phase 3 (wave 0): follow the chain of hand-overs, collect tokens, schedule redos */
+/* phase 3 (wave 0): follow the chain of hand-overs from segment 0 and collect the
+ * tokens; where a parser gave up, ask for a redo round and come back */
 DEV void sg_phase_resolve(const LzJob &job, SgLds *lds, const SgScratch &scr, int w)
 {
     if (w != 0)
         return;
-    uint32_t k = UNI(lds->chain);
+    const uint32_t S0 = UNI(lds->S0);
+    uint32_t k = UNI(lds->chain), ft = UNI(lds->chain_ft);
     for (;;) {
         const uint32_t kind = UNI(lds->wv[k].exit_kind);
         const uint32_t xp = UNI(lds->wv[k].exit_p);
-        sg_append(job, lds, scr.tok + k * SG_TOKCAP, UNI(lds->wv[k].first_tok), UNI(lds->wv[k].ntok), 1);
+        sg_append(job, lds, scr.tok + k * SG_TOKCAP, ft, UNI(lds->wv[k].ntok), 1);
         if (kind == SG_EXIT_SYNCED) {
-            const uint32_t j = k + 1;
-            const uint32_t a_j = UNI(lds->S0) + j * SG_G;
-            const uint32_t ft = UNI(scr.sidx[j * SG_TRACE + (xp - a_j)]);
-            ON_LANE0 { lds->wv[j].first_tok = ft; }
-            WAVE_SYNC();
-            k = j;
+            const uint32_t t = (xp - S0) / SG_G;
+            ft = UNI(scr.sidx[t * SG_TRACE + (xp - S0) % SG_G]);
+            k = t;
             continue;
         }
         if (kind == SG_EXIT_UNSYNCED) {
-            /* the next segment is parsed again, this time from the true state */
-            const uint32_t j = k + 1;
+            /* xp < end of the super-step, so it lies in a later segment of it */
             ON_LANE0
             {
-                lds->wv[j].run = 1;
-                lds->wv[j].start_p = xp;
-                lds->wv[j].start_len = lds->wv[k].exit_len;
-                lds->wv[j].start_at = lds->wv[k].exit_at;
-                lds->wv[j].start_pending = lds->wv[k].exit_pending;
-                lds->wv[j].first_tok = 0;
-                lds->chain = j;
-                lds->again = 1;
+                lds->redo = 1;
+                lds->redo_from = k;
+                lds->redo_seg = (xp - S0) / SG_G;
+                lds->chain = (xp - S0) / SG_G;
+                lds->chain_ft = 0;
             }
             WAVE_SYNC();
             return;
@@ -414,7 +691,7 @@ DEV void sg_phase_resolve(const LzJob &job, SgLds *lds, const SgScratch &scr, in
                 lds->wv[0].start_at = lds->wv[k].exit_at;
                 lds->wv[0].start_pending = lds->wv[k].exit_pending;
                 lds->S0 += SG_SPAN;
-                lds->again = 0;
+                lds->redo = 0;
             }
             WAVE_SYNC();
             return;
@@ -439,7 +716,7 @@ DEV void sg_phase_resolve(const LzJob &job, SgLds *lds, const SgScratch &scr, in
             b->last = 1;
             job.out->nsyms = lds->nsyms;
             job.out->nblocks = lds->nblocks + 1;
-            lds->again = 0;
+            lds->redo = 0;
             lds->finished = 1;
         }
         WAVE_SYNC();
@@ -455,9 +732,12 @@ DEV void sg_init(SgLds *lds, int w)
     ON_LANE0
     {
         lds->S0 = 0;
-        lds->again = 0;
         lds->finished = 0;
-        lds->chain = 0;
+        lds->queue = 0;
+        lds->redo = 0;
+        lds->redo_seg = lds->redo_from = 0;
+        lds->chain = lds->chain_ft = 0;
+        lds->emu_ascending = 0;
         lds->lo = lds->hi = lds->wrap_base = 0;
         lds->nsyms = lds->nblocks = lds->blk_sym0 = lds->blk_in0 = lds->cov = 0;
         lds->wv[0].start_p = 0;

@@ -92,6 +92,7 @@ static inline uint32_t ld_u16(const uint8_t *p)
     return v;
 }
 #define LDS_ADD_U32(ptr, v) (*(ptr) += (v))
+#define LDS_FETCH_ADD_U32(ptr, v) ((*(ptr) += (v)) - (v)) /* returns the old value */
 #define LDS_OR_U32(ptr, v) (*(ptr) |= (v))
 #define GLOBAL_OR_U32(ptr, v) (*(ptr) |= (v))
 #define CTZ64(x) __builtin_ctzll(x)
@@ -166,6 +167,7 @@ DEV uint32_t ld_u16(const uint8_t *p)
     return v;
 }
 #define LDS_ADD_U32(ptr, v) atomicAdd((ptr), (v))
+#define LDS_FETCH_ADD_U32(ptr, v) atomicAdd((ptr), (v))
 #define LDS_OR_U32(ptr, v) atomicOr((ptr), (v))
 #define GLOBAL_OR_U32(ptr, v) atomicOr((ptr), (v))
 #define CTZ64(x) __builtin_ctzll(x)

@@ -76,9 +76,10 @@ __global__ __launch_bounds__(HS_WAVES * 64) void k_hash_sort(
     job.sorted = sorted + (uint64_t)tile * ZD_TILE;
     job.tmp = tmp + (uint64_t)tile * ZD_TILE;
     job.rank = rank + buf.rank_off;
-    job.dir = (t + 1 < buf.ntiles) ? dir + (uint64_t)tile * ZD_DIR_STRIDE : nullptr;
+    job.dir = dir + (uint64_t)tile * ZD_DIR_STRIDE;
     job.dir_prev = nullptr;
     job.hib = nullptr;
+    job.cnt = nullptr;
     const int w = (int)(threadIdx.x >> 6);
     for (int phase = 0; phase < HS_PHASES; phase++) {
         hash_sort_phase(job, &lds, w, phase);
@@ -86,19 +87,18 @@ __global__ __launch_bounds__(HS_WAVES * 64) void k_hash_sort(
     }
 }
 
-/* kernel 1b: one workgroup per tile that has a predecessor in its buffer */
+/* kernel 1b: one workgroup per tile: chain lengths, and the link into the previous tile */
 __global__ __launch_bounds__(HS_WAVES * 64) void k_link_prev(
     const uint8_t *__restrict__ in, const ZdBuf *__restrict__ bufs,
     const uint32_t *__restrict__ tile_owner, const uint16_t *__restrict__ dir,
-    uint16_t *__restrict__ hib, uint32_t ntiles)
+    const uint16_t *__restrict__ rank, uint16_t *__restrict__ hib, uint32_t *__restrict__ cnt,
+    uint32_t ntiles)
 {
     const uint32_t tile = blockIdx.x;
     if (tile >= ntiles)
         return;
     const ZdBuf buf = bufs[tile_owner[tile]];
     const uint32_t t = tile - buf.tile0;
-    if (t == 0)
-        return;
     HsTile job;
     job.in = in + buf.in_off;
     job.n = buf.in_len;
@@ -107,10 +107,11 @@ __global__ __launch_bounds__(HS_WAVES * 64) void k_link_prev(
     job.m = owners > job.start ? min(owners - job.start, ZD_TILE) : 0u;
     job.sorted = nullptr;
     job.tmp = nullptr;
-    job.rank = nullptr;
-    job.dir = nullptr;
-    job.dir_prev = dir + (uint64_t)(tile - 1) * ZD_DIR_STRIDE;
+    job.rank = const_cast<uint16_t *>(rank) + buf.rank_off;
+    job.dir = const_cast<uint16_t *>(dir) + (uint64_t)tile * ZD_DIR_STRIDE;
+    job.dir_prev = t ? dir + (uint64_t)(tile - 1) * ZD_DIR_STRIDE : nullptr;
     job.hib = hib + buf.rank_off;
+    job.cnt = cnt + buf.rank_off;
     hs_link_prev(job, (int)(threadIdx.x >> 6));
 }
 
@@ -140,6 +141,7 @@ __global__ __launch_bounds__(64) void k_parse(const uint8_t *__restrict__ in,
     job.sorted = sorted + (uint64_t)buf.tile0 * ZD_TILE;
     job.rank = rank + buf.rank_off;
     job.hib = hib + buf.rank_off;
+    job.cnt = nullptr;
     job.syms = syms + buf.sym_off;
     job.blocks = recs + buf.blk0;
     job.out = pout + b;
@@ -156,6 +158,7 @@ __global__ __launch_bounds__(SG_W * 64, 6) void k_parse_seg(const uint8_t *__res
                                                          const uint32_t *__restrict__ sorted,
                                                          const uint16_t *__restrict__ rank,
                                                          const uint16_t *__restrict__ hib,
+                                                         const uint32_t *__restrict__ cnt,
                                                          uint32_t *__restrict__ syms,
                                                          ZdBlockRec *__restrict__ recs,
                                                          ZdParseOut *__restrict__ pout,
@@ -175,19 +178,20 @@ __global__ __launch_bounds__(SG_W * 64, 6) void k_parse_seg(const uint8_t *__res
     job.sorted = sorted + (uint64_t)buf.tile0 * ZD_TILE;
     job.rank = rank + buf.rank_off;
     job.hib = hib + buf.rank_off;
+    job.cnt = cnt + buf.rank_off;
     job.syms = syms + buf.sym_off;
     job.blocks = recs + buf.blk0;
     job.out = pout + b;
     job.cfg = cfg;
     job.strategy = buf.strategy;
     SgScratch scr;
-    scr.tok = seg_tok + (uint64_t)blockIdx.x * (SG_W * SG_TOKCAP);
-    scr.sidx = seg_sidx + (uint64_t)blockIdx.x * (SG_W * SG_TRACE);
+    scr.tok = seg_tok + (uint64_t)blockIdx.x * (SG_NS * SG_TOKCAP);
+    scr.sidx = seg_sidx + (uint64_t)blockIdx.x * (SG_NS * SG_TRACE);
     const int w = (int)(threadIdx.x >> 6);
     sg_init(&lds, w);
     __syncthreads();
     /* every loop is bounded so that a logic error can never hang the device: a buffer
-     * needs n/SG_SPAN + 1 super-steps and a super-step at most SG_W parse rounds */
+     * needs n/SG_SPAN + 1 super-steps */
     const uint32_t max_steps = buf.in_len / SG_SPAN + 2;
     uint32_t steps = 0;
     bool stuck = false;
@@ -198,9 +202,11 @@ __global__ __launch_bounds__(SG_W * 64, 6) void k_parse_seg(const uint8_t *__res
         }
         sg_phase_begin(job, &lds, w);
         __syncthreads();
+        /* a redo round follows whenever a parser gave up before it met a successor's
+         * tokens; each one moves the resolver at least one segment on */
         uint32_t rounds = 0;
         do {
-            if (++rounds > SG_W + 1) {
+            if (++rounds > SG_NS + 1) {
                 stuck = true;
                 break;
             }
@@ -208,7 +214,7 @@ __global__ __launch_bounds__(SG_W * 64, 6) void k_parse_seg(const uint8_t *__res
             __syncthreads();
             sg_phase_resolve(job, &lds, scr, w);
             __syncthreads();
-        } while (lds.again);
+        } while (lds.redo);
         if (stuck)
             break;
     }
@@ -241,6 +247,7 @@ __global__ __launch_bounds__(64) void k_parse_fast(const uint8_t *__restrict__ i
     job.sorted = sorted + (uint64_t)buf.tile0 * ZD_TILE;
     job.rank = rank + buf.rank_off;
     job.hib = hib + buf.rank_off;
+    job.cnt = nullptr;
     job.syms = syms + buf.sym_off;
     job.blocks = recs + buf.blk0;
     job.out = pout + b;
@@ -439,7 +446,7 @@ struct zsc_hip_deflate_plan {
     std::vector<ZdBuf> bufs; /* in_off / out_off are absolute in the caller's buffers */
     std::vector<SubBatch> subs;
     /* scratch shared by all sub-batches (sized for the largest) */
-    DevBuf d_sorted, d_tmp_syms, d_rank, d_hib, d_dir, d_recs, d_plans, d_pout;
+    DevBuf d_sorted, d_tmp_syms, d_rank, d_hib, d_cnt, d_dir, d_recs, d_plans, d_pout;
     DevBuf d_seg_tok, d_seg_sidx; /* per long buffer: token staging of the segmented parser */
     bool use_seg = true;
     DevBuf d_res; /* one ZdResult per buffer of the whole plan */
@@ -543,7 +550,7 @@ extern "C" ZlibReturn zsc_hip_deflate_plan_create(zsc_hip_deflate_plan **plan_ou
     pl->strategy = (uint32_t)strategy;
     pl->bufs.resize(count);
 
-    uint64_t sub_limit = 16384ull << 20; /* input bytes per sub-batch (scratch is ~10 B per input byte) */
+    uint64_t sub_limit = 8192ull << 20; /* input bytes per sub-batch (scratch is ~16 B per input byte) */
     if (const char *e = getenv("ZSC_HIP_SUBBATCH_MB"))
         sub_limit = (uint64_t)atoll(e) << 20;
     if (sub_limit < (1ull << 20))
@@ -649,8 +656,8 @@ extern "C" ZlibReturn zsc_hip_deflate_plan_create(zsc_hip_deflate_plan **plan_ou
     for (const SubBatch &sb : pl->subs)
         max_seg = std::max<uint64_t>(max_seg, sb.c36);
     if (pl->use_seg && max_seg) {
-        if (!pl->d_seg_tok.ensure(max_seg * SG_W * SG_TOKCAP * 4ull) ||
-            !pl->d_seg_sidx.ensure(max_seg * SG_W * SG_TRACE * 2ull)) {
+        if (!pl->d_seg_tok.ensure(max_seg * SG_NS * SG_TOKCAP * 4ull) ||
+            !pl->d_seg_sidx.ensure(max_seg * SG_NS * SG_TRACE * 2ull)) {
             zsc_hip_deflate_plan_destroy(pl);
             return Z_MEM_ERROR;
         }
@@ -664,6 +671,7 @@ extern "C" ZlibReturn zsc_hip_deflate_plan_create(zsc_hip_deflate_plan **plan_ou
     bool ok = pl->d_sorted.ensure(tile_words * 4) &&
               pl->d_tmp_syms.ensure(std::max<uint64_t>(tile_words, max_syms) * 4) &&
               pl->d_rank.ensure(max_rank_span * 2) && pl->d_hib.ensure(max_rank_span * 2) &&
+              pl->d_cnt.ensure(max_rank_span * 4) &&
               pl->d_dir.ensure(max_tiles * ZD_DIR_STRIDE * 2) &&
               pl->d_recs.ensure(max_slots * sizeof(ZdBlockRec)) &&
               pl->d_plans.ensure(max_slots * sizeof(ZdBlockPlan)) &&
@@ -673,7 +681,7 @@ extern "C" ZlibReturn zsc_hip_deflate_plan_create(zsc_hip_deflate_plan **plan_ou
         zsc_hip_deflate_plan_destroy(pl);
         return Z_MEM_ERROR;
     }
-    pl->scratch_bytes += pl->d_sorted.bytes + pl->d_tmp_syms.bytes + pl->d_rank.bytes + pl->d_hib.bytes +
+    pl->scratch_bytes += pl->d_sorted.bytes + pl->d_tmp_syms.bytes + pl->d_rank.bytes + pl->d_hib.bytes + pl->d_cnt.bytes +
                          pl->d_dir.bytes + pl->d_recs.bytes + pl->d_plans.bytes +
                          pl->d_pout.bytes + pl->d_res.bytes;
     *plan_out = pl;
@@ -721,6 +729,7 @@ extern "C" ZlibReturn zsc_hip_deflate_plan_run(zsc_hip_deflate_plan *pl, const v
         uint32_t *tmp_syms = (uint32_t *)pl->d_tmp_syms.p;
         uint16_t *rank = (uint16_t *)pl->d_rank.p;
         uint16_t *hib = (uint16_t *)pl->d_hib.p;
+        uint32_t *cnt = (uint32_t *)pl->d_cnt.p;
         uint16_t *dir = (uint16_t *)pl->d_dir.p;
         ZdBlockRec *recs = (ZdBlockRec *)pl->d_recs.p;
         ZdBlockPlan *plans = (ZdBlockPlan *)pl->d_plans.p;
@@ -733,7 +742,8 @@ extern "C" ZlibReturn zsc_hip_deflate_plan_run(zsc_hip_deflate_plan *pl, const v
                            (const uint32_t *)sb.d_tile_owner.p, sorted, tmp_syms, rank, dir,
                            sb.ntiles);
         hipLaunchKernelGGL(k_link_prev, dim3(sb.ntiles), dim3(HS_WAVES * 64), 0, st, in, bufs,
-                           (const uint32_t *)sb.d_tile_owner.p, (const uint16_t *)dir, hib,
+                           (const uint32_t *)sb.d_tile_owner.p, (const uint16_t *)dir,
+                           (const uint16_t *)rank, hib, cnt,
                            sb.ntiles);
         mark();
         if (cfg.slow) {
@@ -746,7 +756,8 @@ extern "C" ZlibReturn zsc_hip_deflate_plan_run(zsc_hip_deflate_plan *pl, const v
             if (pl->use_seg && sb.c36 > 0)
                 hipLaunchKernelGGL(k_parse_seg, dim3(sb.c36), dim3(SG_W * 64), 0, st, in, bufs,
                                    (const uint32_t *)sb.d_order.p, (const uint32_t *)sorted,
-                                   (const uint16_t *)rank, (const uint16_t *)hib, tmp_syms, recs,
+                                   (const uint16_t *)rank, (const uint16_t *)hib,
+                                   (const uint32_t *)cnt, tmp_syms, recs,
                                    pout, (uint32_t *)pl->d_seg_tok.p, (uint16_t *)pl->d_seg_sidx.p,
                                    cfg, 0u, sb.c36);
             else
@@ -848,6 +859,7 @@ extern "C" void zsc_hip_deflate_plan_destroy(zsc_hip_deflate_plan *pl)
     pl->d_tmp_syms.release();
     pl->d_rank.release();
     pl->d_hib.release();
+    pl->d_cnt.release();
     pl->d_seg_tok.release();
     pl->d_seg_sidx.release();
     pl->d_dir.release();
