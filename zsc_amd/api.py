@@ -23,7 +23,7 @@ NKERNELS = 7
 KERNEL_NAMES = ("checksum", "hash_sort", "parse", "huff_plan", "layout", "emit", "total")
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-lib_path = os.path.join(_HERE, "libzsc_hip.so")
+lib_path = os.environ.get("ZSC_HIP_LIB") or os.path.join(_HERE, "libzsc_hip.so")  # env: experiments only
 
 
 def build_library() -> None:

@@ -39,8 +39,12 @@
 #define SG_COUNT(what, n) /* event counters of the host emulation (tests/emu) */
 #endif
 
+#ifndef SG_W
 #define SG_W 8                      /* waves per workgroup */
+#endif
+#ifndef SG_G
 #define SG_G 256u                   /* positions per segment */
+#endif
 #define SG_SPAN 8192u               /* positions per super-step */
 #define SG_NS (SG_SPAN / SG_G)      /* segments per super-step, handed to the waves by a work queue */
 #define SG_OV 512u                  /* how far past its segment a parser looks for a hand-over */
@@ -165,20 +169,52 @@ DEV void sg_phase_begin(const LzJob &job, SgLds *lds, int w)
         }                                                                                     \
     } while (0)
 
+/* entries of candidates 64*B .. 64*B+63; lanes past the end of the chain read entry 0 of
+ * the tile (a valid address) and are masked later -- cheaper than predicating the load */
 #define SG_LOAD(E, B)                                                                         \
     FOR_LANES                                                                                 \
     {                                                                                         \
         const uint32_t _v = (B)*64u + (uint32_t)LANE;                                         \
-        uint32_t _e = ZD_ENTRY_NONE;                                                          \
-        if (_v < total) {                                                                     \
-            const int32_t _i = _v < nA ? hiA - (int32_t)_v                                    \
-                                       : hiB - (int32_t)(_v - nA) - (int32_t)ZD_TILE;         \
-            _e = runA[_i];                                                                    \
-        }                                                                                     \
-        LV(E) = _e;                                                                           \
+        int32_t _i = _v < nA ? hiA - (int32_t)_v : hiB - (int32_t)(_v - nA) - (int32_t)ZD_TILE; \
+        _i = _v < total ? _i : 0;                                                             \
+        LV(E) = runA[_i];                                                                     \
     }
 
-/* evaluate candidates 64*B .. 64*B+63 (entries E); sets fin when the search is over */
+/* cooperative longest common prefix of the strings at QJ and p (at most cap bytes) */
+#define SG_LCP(QJ, LEN)                                                                       \
+    do {                                                                                      \
+        SG_COUNT(1, 1);                                                                       \
+        if (pv_at != p) {                                                                     \
+            pv_at = p;                                                                        \
+            FOR_LANES { LV(pv) = ld_u32(&lds->ring[lz_ridx<L>(st, p + 4u * (uint32_t)LANE)]); } \
+        }                                                                                     \
+        LANEVAR(uint32_t, _diff);                                                             \
+        LANEVAR(int, _differs);                                                               \
+        FOR_LANES                                                                             \
+        {                                                                                     \
+            LV(_diff) = ld_u32(&lds->ring[lz_ridx<L>(st, (QJ) + 4u * (uint32_t)LANE)]) ^ LV(pv); \
+            LV(_differs) = LV(_diff) != 0;                                                    \
+        }                                                                                     \
+        const uint64_t _dm = BALLOT(_differs);                                                \
+        if (_dm != 0) {                                                                       \
+            const int _f = CTZ64(_dm);                                                        \
+            (LEN) = 4u * (uint32_t)_f + ((uint32_t)CTZ32(READLANE(_diff, _f)) >> 3);          \
+        } else {                                                                              \
+            (LEN) = 256;                                                                      \
+            if (cap > 256 && UNI(lds->ring[lz_ridx<L>(st, (QJ) + 256)]) ==                    \
+                                 UNI(lds->ring[lz_ridx<L>(st, p + 256)])) {                   \
+                (LEN) = 257;                                                                  \
+                if (cap > 257 && UNI(lds->ring[lz_ridx<L>(st, (QJ) + 257)]) ==                \
+                                     UNI(lds->ring[lz_ridx<L>(st, p + 257)]))                 \
+                    (LEN) = 258;                                                              \
+            }                                                                                 \
+        }                                                                                     \
+        if ((LEN) > cap)                                                                      \
+            (LEN) = cap;                                                                      \
+    } while (0)
+
+/* evaluate candidates 64*B .. 64*B+63 (entries E); sets fin when the search is over.
+ * The chain head (candidate 0) has been checked by the caller. */
 #define SG_EVAL(E, B)                                                                         \
     do {                                                                                      \
         LANEVAR(uint32_t, _q);                                                                \
@@ -191,37 +227,21 @@ DEV void sg_phase_begin(const LzJob &job, SgLds *lds, int w)
             const uint32_t _v = (B)*64u + (uint32_t)LANE;                                     \
             const uint32_t q = tileA + (LV(E) & ZD_TILE_MASK) - (_v < nA ? 0u : ZD_TILE);     \
             LV(_q) = q;                                                                       \
-            /* the chain head may lie at exactly MAX_DIST (:2032), later links may not (:1519) */ \
-            LV(_alive) = _v < total &&                                                        \
-                         (_v == 0 ? (q > st.base && p - q <= ZD_MAX_DIST) : q > floor_pos);   \
+            LV(_alive) = _v == 0 || (_v < total && q > floor_pos); /* :1519 */                \
         }                                                                                     \
         const uint64_t _m_alive = BALLOT(_alive);                                             \
-        if ((B) == 0) {                                                                       \
-            if (!(_m_alive & 1ull)) {                                                         \
-                fin = 2; /* no chain head in the window: longest_match is not called */       \
-                break;                                                                        \
-            }                                                                                 \
-            head_seen = 1;                                                                    \
-            if (best >= look) {                                                               \
-                fin = 1;                                                                      \
-                break;                                                                        \
-            }                                                                                 \
-            SG_PEEK32(p + best - 1, sb);                                                      \
-            sb &= 0xffffu;                                                                    \
-        }                                                                                     \
         SG_COUNT(0, 1);                                                                       \
         FOR_LANES                                                                             \
         {                                                                                     \
-            uint32_t w0 = 0;                                                                  \
-            int c = 0;                                                                        \
-            if (LV(_alive)) {                                                                 \
-                w0 = ld_u32(&lds->ring[lz_ridx<L>(st, LV(_q))]);                              \
-                c = ld_u16(&lds->ring[lz_ridx<L>(st, LV(_q) + best - 1)]) == sb &&            \
-                    (w0 & 0xffffu) == (s0123 & 0xffffu);                                      \
-            }                                                                                 \
+            /* lanes without a live candidate read the start of the ring and are masked */    \
+            const int live = LV(_alive);                                                      \
+            const uint32_t r0 = live ? lz_ridx<L>(st, LV(_q)) : 0u;                           \
+            const uint32_t r1 = live ? lz_ridx<L>(st, LV(_q) + best - 1) : 0u;                \
+            const uint32_t w0 = ld_u32(&lds->ring[r0]);                                       \
+            const uint32_t g1 = ld_u16(&lds->ring[r1]);                                       \
             LV(_w0) = w0;                                                                     \
-            LV(_pass) = c;                                                                    \
-            LV(_maybe) = LV(_alive) && w0 == s0123;                                           \
+            LV(_pass) = live && g1 == sb && (w0 & 0xffffu) == (s0123 & 0xffffu);              \
+            LV(_maybe) = live && w0 == s0123;                                                 \
         }                                                                                     \
         uint64_t _todo = BALLOT(_pass);                                                       \
         const uint64_t _m_maybe = cap > 3u ? BALLOT(_maybe) : 0ull;                           \
@@ -241,36 +261,8 @@ DEV void sg_phase_begin(const LzJob &job, SgLds *lds, int w)
                 break;                                                                        \
             const uint32_t _qj = READLANE(_q, _j);                                            \
             uint32_t _len = 3;                                                                \
-            if ((_m_maybe >> _j) & 1ull) {                                                    \
-                SG_COUNT(1, 1);                                                               \
-                if (pv_at != p) {                                                             \
-                    pv_at = p;                                                                \
-                    FOR_LANES { LV(pv) = ld_u32(&lds->ring[lz_ridx<L>(st, p + 4u * (uint32_t)LANE)]); } \
-                }                                                                             \
-                LANEVAR(uint32_t, _diff);                                                     \
-                LANEVAR(int, _differs);                                                       \
-                FOR_LANES                                                                     \
-                {                                                                             \
-                    LV(_diff) = ld_u32(&lds->ring[lz_ridx<L>(st, _qj + 4u * (uint32_t)LANE)]) ^ LV(pv); \
-                    LV(_differs) = LV(_diff) != 0;                                            \
-                }                                                                             \
-                const uint64_t _dm = BALLOT(_differs);                                        \
-                if (_dm != 0) {                                                               \
-                    const int _f = CTZ64(_dm);                                                \
-                    _len = 4u * (uint32_t)_f + ((uint32_t)CTZ32(READLANE(_diff, _f)) >> 3);   \
-                } else {                                                                      \
-                    _len = 256;                                                               \
-                    if (cap > 256 && UNI(lds->ring[lz_ridx<L>(st, _qj + 256)]) ==             \
-                                         UNI(lds->ring[lz_ridx<L>(st, p + 256)])) {           \
-                        _len = 257;                                                           \
-                        if (cap > 257 && UNI(lds->ring[lz_ridx<L>(st, _qj + 257)]) ==         \
-                                             UNI(lds->ring[lz_ridx<L>(st, p + 257)]))         \
-                            _len = 258;                                                       \
-                    }                                                                         \
-                }                                                                             \
-                if (_len > cap)                                                               \
-                    _len = cap;                                                               \
-            }                                                                                 \
+            if ((_m_maybe >> _j) & 1ull)                                                      \
+                SG_LCP(_qj, _len);                                                            \
             int _improved = 0;                                                                \
             if (_len > best) {                                                                \
                 where = _qj;                                                                  \
@@ -290,10 +282,10 @@ DEV void sg_phase_begin(const LzJob &job, SgLds *lds, int w)
                 sb &= 0xffffu;                                                                \
                 FOR_LANES                                                                     \
                 {                                                                             \
-                    int c = 0;                                                                \
-                    if (LV(_alive) && LANE > _j && (LV(_w0) & 0xffffu) == (s0123 & 0xffffu))  \
-                        c = ld_u16(&lds->ring[lz_ridx<L>(st, LV(_q) + best - 1)]) == sb;      \
-                    LV(_pass) = c;                                                            \
+                    const int live = LV(_alive) && LANE > _j &&                               \
+                                     (LV(_w0) & 0xffffu) == (s0123 & 0xffffu);                \
+                    const uint32_t r1 = live ? lz_ridx<L>(st, LV(_q) + best - 1) : 0u;        \
+                    LV(_pass) = live && ld_u16(&lds->ring[r1]) == sb;                         \
                 }                                                                             \
                 _todo = BALLOT(_pass);                                                        \
             } else {                                                                          \
@@ -305,6 +297,104 @@ DEV void sg_phase_begin(const LzJob &job, SgLds *lds, int w)
             const uint64_t _valid = _left >= 64u ? ~0ull : ((1ull << _left) - 1ull);          \
             if (_m_alive != _valid)                                                           \
                 fin = 1; /* the chain leaves the window (:1519) */                            \
+        }                                                                                     \
+    } while (0)
+
+/* four window positions at once: which of the 16-bit strings at byte offsets 0..3 of the
+ * dword pair (LO, HI) equal the pre-check pair */
+#define SG_M4(LO, HI, K)                                                                      \
+    do {                                                                                      \
+        const uint32_t _a = (LO) ^ _sb2, _b = (((LO) >> 8) | ((HI) << 24)) ^ _sb2;            \
+        _m |= ((uint32_t)((_a & 0xffffu) == 0) | ((uint32_t)((_b & 0xffffu) == 0) << 1) |     \
+               ((uint32_t)((_a >> 16) == 0) << 2) | ((uint32_t)((_b >> 16) == 0) << 3))       \
+              << (4 * (K));                                                                   \
+    } while (0)
+
+/* The same search for a position whose chain is long: instead of following the chain,
+ * sweep the window itself, newest position first, 1024 positions per step, for the two
+ * bytes the pre-check wants to see at best_len-1 (:1462-1465).  A candidate that fails
+ * the pre-check costs the reference nothing -- no chain budget, no effect on best_len --
+ * so only positions that show those two bytes AND start with the same three bytes as p
+ * (what being on p's chain and passing :1466-1467 amounts to) matter, in the same
+ * newest-first order.  A dense bucket costs a walk 64 candidates per step; the sweep
+ * covers them at 1024 positions per step without loading a single chain entry. */
+#define SG_SWEEP(Q0)                                                                          \
+    do {                                                                                      \
+        uint32_t _qn = (Q0);                    /* newest position not looked at yet */      \
+        const uint32_t _qlo = floor_pos + 1u;   /* oldest live position (:1519) */            \
+        while (!fin && _qn >= _qlo) {                                                         \
+            const uint32_t _off = best - 1u;                                                  \
+            const uint32_t _rtop = _qn + _off, _rlo = _qlo + _off;                            \
+            const uint32_t _R0 = _rtop & ~1023u;                                              \
+            const uint32_t _sb2 = sb * 0x10001u;                                              \
+            LANEVAR(uint32_t, _m16);                                                          \
+            LANEVAR(int, _has);                                                               \
+            SG_COUNT(0, 1);                                                                   \
+            FOR_LANES                                                                         \
+            {                                                                                 \
+                const uint32_t _x = _R0 + 16u * (uint32_t)LANE;                               \
+                uint32_t _m = 0;                                                              \
+                if (_x <= _rtop && _x + 16u > _rlo) {                                         \
+                    const uint8_t *_src = &lds->ring[lz_ridx<L>(st, _x)];                     \
+                    const uint32_t _w0 = ld_u32(_src), _w1 = ld_u32(_src + 4),                \
+                                   _w2 = ld_u32(_src + 8), _w3 = ld_u32(_src + 12),           \
+                                   _w4 = ld_u32(_src + 16);                                   \
+                    SG_M4(_w0, _w1, 0);                                                       \
+                    SG_M4(_w1, _w2, 1);                                                       \
+                    SG_M4(_w2, _w3, 2);                                                       \
+                    SG_M4(_w3, _w4, 3);                                                       \
+                    const uint32_t _hj = _rtop - _x >= 15u ? 15u : _rtop - _x;                \
+                    const uint32_t _lj = _rlo > _x ? _rlo - _x : 0u;                          \
+                    _m &= ((2u << _hj) - 1u) & ~((1u << _lj) - 1u);                           \
+                }                                                                             \
+                LV(_m16) = _m;                                                                \
+                LV(_has) = _m != 0;                                                           \
+            }                                                                                 \
+            uint64_t _any = BALLOT(_has);                                                     \
+            int _moved = 0;                                                                   \
+            while (_any != 0 && !_moved) {                                                    \
+                const int _l = 63 - CLZ64(_any);                                              \
+                uint32_t _mm = READLANE(_m16, _l);                                            \
+                while (_mm != 0) {                                                            \
+                    const int _j = 31 - CLZ32(_mm);                                           \
+                    _mm &= ~(1u << _j);                                                       \
+                    const uint32_t _qj = _R0 + 16u * (uint32_t)_l + (uint32_t)_j - _off;      \
+                    const uint32_t _t = UNI(ld_u32(&lds->ring[lz_ridx<L>(st, _qj)]));         \
+                    if (((_t ^ s0123) & 0xffffffu) != 0)                                      \
+                        continue; /* not on p's chain, or fails :1466-1467 */                 \
+                    uint32_t _len = 3;                                                        \
+                    if (cap > 3u && _t == s0123)                                              \
+                        SG_LCP(_qj, _len);                                                    \
+                    if (_len > best) {                                                        \
+                        where = _qj;                                                          \
+                        best = _len;                                                          \
+                        _moved = 1;                                                           \
+                        if (_len >= nice) {                                                   \
+                            fin = 1;                                                          \
+                            break;                                                            \
+                        }                                                                     \
+                    }                                                                         \
+                    if (--budget == 0) {                                                      \
+                        fin = 1;                                                              \
+                        break;                                                                \
+                    }                                                                         \
+                    if (_moved) {                                                             \
+                        /* new best_len: other bytes at another offset from here on */        \
+                        SG_PEEK32(p + best - 1, sb);                                          \
+                        sb &= 0xffffu;                                                        \
+                        _qn = _qj - 1u;                                                       \
+                        break;                                                                \
+                    }                                                                         \
+                }                                                                             \
+                if (fin)                                                                      \
+                    break;                                                                    \
+                _any &= ~(1ull << _l);                                                        \
+            }                                                                                 \
+            if (fin || _moved)                                                                \
+                continue;                                                                     \
+            if (_R0 <= _rlo)                                                                  \
+                break; /* the sweep reached the far end of the window */                      \
+            _qn = _R0 - 1u - _off;                                                            \
         }                                                                                     \
     } while (0)
 
@@ -451,30 +541,48 @@ DEV void sg_parse_segment(const LzJob &job, SgLds *lds, const SgScratch &scr, ui
                 SG_LOAD(e1, 1u);
                 SG_LOAD(e2, 2u);
                 SG_LOAD(e3, 3u);
-                for (uint32_t b0 = 0;; b0 += 4u) {
-                    const int more = (b0 + 4u) * 64u < total;
-                    if (more) {
-                        /* the next 256 candidates are on their way while these are looked at */
-                        SG_LOAD(f0, b0 + 4u);
-                        SG_LOAD(f1, b0 + 5u);
-                        SG_LOAD(f2, b0 + 6u);
-                        SG_LOAD(f3, b0 + 7u);
-                    }
-                    SG_EVAL(e0, b0);
-                    if (!fin && (b0 + 1u) * 64u < total)
-                        SG_EVAL(e1, b0 + 1u);
-                    if (!fin && (b0 + 2u) * 64u < total)
-                        SG_EVAL(e2, b0 + 2u);
-                    if (!fin && (b0 + 3u) * 64u < total)
-                        SG_EVAL(e3, b0 + 3u);
-                    if (fin || !more)
-                        break;
-                    FOR_LANES
-                    {
-                        LV(e0) = LV(f0);
-                        LV(e1) = LV(f1);
-                        LV(e2) = LV(f2);
-                        LV(e3) = LV(f3);
+                /* the chain head may lie at exactly MAX_DIST (:2032), later links may not */
+                const uint32_t ent0 = READLANE(e0, 0);
+                const uint32_t q0 = tileA + (ent0 & ZD_TILE_MASK) - (nA ? 0u : ZD_TILE);
+                if (!(q0 > st.base && p - q0 <= ZD_MAX_DIST)) {
+                    fin = 2; /* no chain head in the window: longest_match is not called */
+                } else {
+                    head_seen = 1;
+                    if (best >= look)
+                        fin = 1;
+                }
+                if (!fin) {
+                    SG_PEEK32(p + best - 1, sb);
+                    sb &= 0xffffu;
+                }
+                if (!fin && q0 > floor_pos && total > 128u * ((q0 - floor_pos) / 1024u + 2u)) {
+                    SG_SWEEP(q0);
+                } else if (!fin) {
+                    for (uint32_t b0 = 0;; b0 += 4u) {
+                        const int more = (b0 + 4u) * 64u < total;
+                        if (more) {
+                            /* the next 256 candidates are on their way while these are looked at */
+                            SG_LOAD(f0, b0 + 4u);
+                            SG_LOAD(f1, b0 + 5u);
+                            SG_LOAD(f2, b0 + 6u);
+                            SG_LOAD(f3, b0 + 7u);
+                        }
+                        SG_EVAL(e0, b0);
+                        if (!fin && (b0 + 1u) * 64u < total)
+                            SG_EVAL(e1, b0 + 1u);
+                        if (!fin && (b0 + 2u) * 64u < total)
+                            SG_EVAL(e2, b0 + 2u);
+                        if (!fin && (b0 + 3u) * 64u < total)
+                            SG_EVAL(e3, b0 + 3u);
+                        if (fin || !more)
+                            break;
+                        FOR_LANES
+                        {
+                            LV(e0) = LV(f0);
+                            LV(e1) = LV(f1);
+                            LV(e2) = LV(f2);
+                            LV(e3) = LV(f3);
+                        }
                     }
                 }
                 if (fin != 2 && head_seen) {

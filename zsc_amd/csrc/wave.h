@@ -98,6 +98,8 @@ static inline uint32_t ld_u16(const uint8_t *p)
 #define CTZ64(x) __builtin_ctzll(x)
 #define CTZ32(x) __builtin_ctz(x)
 #define POPC64(x) __builtin_popcountll(x)
+#define CLZ64(x) __builtin_clzll(x)
+#define CLZ32(x) __builtin_clz(x)
 #define COPY16(dst, src) memcpy((dst), (src), 16)
 #define UNI(x) (x)
 
@@ -173,6 +175,8 @@ DEV uint32_t ld_u16(const uint8_t *p)
 #define CTZ64(x) __builtin_ctzll(x)
 #define CTZ32(x) __builtin_ctz(x)
 #define POPC64(x) __builtin_popcountll(x)
+#define CLZ64(x) __builtin_clzll(x)
+#define CLZ32(x) __builtin_clz(x)
 /* A value that is the same in every lane but was produced by a vector instruction
  * (an LDS or global load from a wave-uniform address): move it to an SGPR, so that
  * branches on it are scalar branches instead of exec-mask regions and arithmetic on
