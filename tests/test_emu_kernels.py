@@ -76,3 +76,26 @@ def test_full_pipeline_streams(emu, oracle):
                 rc, got = emu_compress(emu, data, level, wrap, strat)
                 orc, want, _ = oracle.compress(data, level, window_bits=wb, strategy=strat)
                 assert rc == orc == 0 and got == want, (n, kind, level, wrap, strat)
+
+
+def test_segmented_parser_hand_over_orders(emu, oracle):
+    """The multi-wave parser (lz_parse_seg.h) for long buffers: segments are parsed
+    speculatively and stitched together.  Mode 2 hands segments out last-first (every
+    parser finds its successors' traces, the GPU's normal case), mode 3 first-first (no
+    trace is ever there in time: every hand-over is a give-up + redo).  Both must give
+    the serial parse's stream, on data that resyncs at once (text), never (zero, runs),
+    and on long hash chains that take the window-sweep path (bitmap)."""
+    try:
+        for mode in (2, 3):
+            emu.emu_set_seg_mode(mode)
+            for n in (0, 3, 255, 256, 257, 1025, 8191, 8193, 40000, 70000, 140000):
+                for kind in ("text", "bitmap", "zero", "runs", "table", "random"):
+                    if n > 70000 and kind not in ("text", "bitmap", "zero"):
+                        continue
+                    data = corpus.make_buffer(kind, n, n + 17)
+                    for level in (6, 9, 4) if n <= 40000 else (6,):
+                        rc, got = emu_compress(emu, data, level, 1)
+                        orc, want, _ = oracle.compress(data, level)
+                        assert rc == orc == 0 and got == want, (mode, n, kind, level)
+    finally:
+        emu.emu_set_seg_mode(0)

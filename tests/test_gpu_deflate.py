@@ -139,3 +139,22 @@ def test_device_plan_large_batch_properties(z, oracle):
             assert oracle.uncompress(stream, len(b)) == (0, b, ln)
             assert stream == oracle.compress(b, 6)[1]
     plan.close()
+
+
+def test_config3_mix_of_64k_buffers_levels_1_6_9(z, oracle):
+    """BASELINE config 3: 64 KiB random + zero + text buffers at levels 1, 6 and 9.  A batch
+    the oracle can follow is compared byte for byte; a larger one is checked by round trip
+    through the GPU inflate and by "same input, same stream"."""
+    small = corpus.mix64k(48, seed=5)
+    for level in (1, 6, 9):
+        rc, outs, stats = z.compress_batch(small, level=level)
+        assert rc == 0 and all(s == 0 for s in stats)
+        for b, o in zip(small, outs):
+            assert o == oracle.compress(b, level)[1], level
+    big = corpus.mix64k(96, seed=9) * 8          # 768 buffers, 48 MiB
+    for level in (1, 6, 9):
+        rc, outs, stats = z.compress_batch(big, level=level)
+        assert rc == 0 and all(s == 0 for s in stats)
+        assert outs[:96] == outs[96:192] == outs[-96:]
+        rc, back, _, st = z.uncompress_batch(outs[:96], [65536] * 96)
+        assert rc == 0 and all(s == 0 for s in st) and back == big[:96]

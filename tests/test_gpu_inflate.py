@@ -75,3 +75,17 @@ def test_deflate_then_inflate_on_gpu_is_identity(z):
     assert rc == 0
     for b, c, o, u, s in zip(bufs, comps, outs, used, stats):
         assert (s, o, u) == (0, b, len(c))
+
+
+def test_config4_many_gzip_chunks(z, oracle):
+    """BASELINE config 4 (scaled to what the CPU checker can prepare): thousands of
+    independent gzip members of 4..64 KiB through one batched inflate call."""
+    import random
+    rnd = random.Random(4)
+    kinds = ("text", "token", "table", "bitmap", "object", "random", "zero")
+    plain = [corpus.make_buffer(kinds[i % len(kinds)], rnd.randrange(4096, 65537), 100 + i) for i in range(160)]
+    gz = [oracle.compress(b, (1, 6, 9)[i % 3], window_bits=31)[1] for i, b in enumerate(plain)]
+    reps = 16                                     # 2560 streams
+    rc, outs, _, stats = z.uncompress_batch(gz * reps, [len(b) for b in plain] * reps, window_bits=31)
+    assert rc == 0 and all(s == 0 for s in stats)
+    assert outs == plain * reps

@@ -19,8 +19,8 @@ Z_OK, Z_STREAM_END, Z_NEED_DICT = 0, 1, 2
 Z_ERRNO, Z_STREAM_ERROR, Z_DATA_ERROR, Z_MEM_ERROR, Z_BUF_ERROR, Z_VERSION_ERROR = -1, -2, -3, -4, -5, -6
 Z_DEFAULT_STRATEGY, Z_FILTERED, Z_HUFFMAN_ONLY, Z_RLE, Z_FIXED = 0, 1, 2, 3, 4
 GZIP_CODE, DEF_WBITS, DEF_MEM_LEVEL = 16, 15, 8
-NKERNELS = 7
-KERNEL_NAMES = ("checksum", "hash_sort", "parse", "huff_plan", "layout", "emit", "total")
+NKERNELS = 8
+KERNEL_NAMES = ("checksum", "hash_sort", "parse", "parse_short", "huff_plan", "layout", "emit", "total")
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 lib_path = os.environ.get("ZSC_HIP_LIB") or os.path.join(_HERE, "libzsc_hip.so")  # env: experiments only
@@ -82,6 +82,8 @@ def _load() -> C.CDLL:
     L.zsc_hip_deflate_plan_times.argtypes = [C.c_void_p, C.POINTER(C.c_float)]
     L.zsc_hip_deflate_plan_scratch_bytes.argtypes = [C.c_void_p]
     L.zsc_hip_deflate_plan_scratch_bytes.restype = C.c_uint64
+    L.zsc_hip_deflate_plan_sub_batches.argtypes = [C.c_void_p]
+    L.zsc_hip_deflate_plan_sub_batches.restype = C.c_uint32
     L.zsc_hip_deflate_plan_destroy.argtypes = [C.c_void_p]
     L.zsc_hip_deflate_plan_destroy.restype = None
     return L
@@ -298,6 +300,10 @@ class DeflatePlan:
     @property
     def scratch_bytes(self) -> int:
         return lib.zsc_hip_deflate_plan_scratch_bytes(self._h)
+
+    @property
+    def sub_batches(self) -> int:
+        return lib.zsc_hip_deflate_plan_sub_batches(self._h)
 
     def profile(self, enable: bool = True) -> None:
         lib.zsc_hip_deflate_plan_profile(self._h, 1 if enable else 0)

@@ -453,7 +453,7 @@ struct zsc_hip_deflate_plan {
     uint64_t rank_base_off = 0;
     bool profile = false;
     float times[ZSC_HIP_NKERNELS] = {0};
-    std::vector<hipEvent_t> events; /* 7 per sub-batch per profiled run */
+    std::vector<hipEvent_t> events; /* ZSC_HIP_NKERNELS per sub-batch per profiled run */
     size_t events_used = 0;
     uint32_t profiled_runs = 0;
     hipStream_t last_stream = nullptr;
@@ -708,7 +708,7 @@ extern "C" ZlibReturn zsc_hip_deflate_plan_run(zsc_hip_deflate_plan *pl, const v
     uint8_t *out = (uint8_t *)d_output;
     const ZdLevel cfg = kLevels[pl->level];
 
-    const size_t nev = pl->events_used + pl->subs.size() * 7;
+    const size_t nev = pl->events_used + pl->subs.size() * ZSC_HIP_NKERNELS;
     if (pl->profile) {
         while (pl->events.size() < nev) {
             hipEvent_t e;
@@ -762,6 +762,7 @@ extern "C" ZlibReturn zsc_hip_deflate_plan_run(zsc_hip_deflate_plan *pl, const v
                                    cfg, 0u, sb.c36);
             else
                 ZSC_LAUNCH_PARSE(LzLds, 0, sb.c36);
+            mark();
             ZSC_LAUNCH_PARSE(LzLds16k, sb.c36, sb.c16 - sb.c36);
             ZSC_LAUNCH_PARSE(LzLds8k, sb.c16, sb.c8 - sb.c16);
             ZSC_LAUNCH_PARSE(LzLds4k, sb.c8, sb.count - sb.c8);
@@ -771,6 +772,8 @@ extern "C" ZlibReturn zsc_hip_deflate_plan_run(zsc_hip_deflate_plan *pl, const v
                                (const uint32_t *)sb.d_order.p, (const uint32_t *)sorted,
                                (const uint16_t *)rank, (const uint16_t *)hib, tmp_syms, recs,
                                pout, cfg, sb.count);
+        if (!cfg.slow)
+            mark(); /* levels 1-3: one parse kernel for every length, the short-buffer slot stays empty */
         mark();
         hipLaunchKernelGGL(k_huff_plan, dim3(sb.nslots), dim3(64), 0, st, bufs,
                            (const uint32_t *)sb.d_blk_owner.p, (const uint32_t *)tmp_syms,
@@ -810,20 +813,21 @@ extern "C" ZlibReturn zsc_hip_deflate_plan_results(zsc_hip_deflate_plan *pl, U32
         /* mean per run over every run since profiling was switched on */
         for (int k = 0; k < ZSC_HIP_NKERNELS; k++)
             pl->times[k] = 0.f;
-        const size_t per_run = pl->subs.size() * 7;
+        const int NE = ZSC_HIP_NKERNELS; /* marks per sub-batch: NE-1 intervals + the whole pass */
+        const size_t per_run = pl->subs.size() * NE;
         for (uint32_t r = 0; r < pl->profiled_runs; r++) {
             const size_t e0 = (size_t)r * per_run;
             for (size_t s = 0; s < pl->subs.size(); s++) {
-                for (int k = 0; k < 6; k++) {
+                for (int k = 0; k < NE - 1; k++) {
                     float ms = 0.f;
-                    (void)hipEventElapsedTime(&ms, pl->events[e0 + s * 7 + k],
-                                              pl->events[e0 + s * 7 + k + 1]);
+                    (void)hipEventElapsedTime(&ms, pl->events[e0 + s * NE + k],
+                                              pl->events[e0 + s * NE + k + 1]);
                     pl->times[k] += ms;
                 }
             }
             float ms = 0.f;
             (void)hipEventElapsedTime(&ms, pl->events[e0], pl->events[e0 + per_run - 1]);
-            pl->times[6] += ms;
+            pl->times[NE - 1] += ms;
         }
         for (int k = 0; k < ZSC_HIP_NKERNELS; k++)
             pl->times[k] /= (float)pl->profiled_runs;
@@ -843,6 +847,11 @@ extern "C" ZlibReturn zsc_hip_deflate_plan_times(zsc_hip_deflate_plan *pl, float
 extern "C" uint64_t zsc_hip_deflate_plan_scratch_bytes(const zsc_hip_deflate_plan *pl)
 {
     return pl ? pl->scratch_bytes : 0;
+}
+
+extern "C" U32 zsc_hip_deflate_plan_sub_batches(const zsc_hip_deflate_plan *pl)
+{
+    return pl ? (U32)pl->subs.size() : 0;
 }
 
 extern "C" void zsc_hip_deflate_plan_destroy(zsc_hip_deflate_plan *pl)
