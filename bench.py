@@ -246,7 +246,7 @@ def main() -> None:
             pmc = json.load(open(os.path.join(ROOT, "profiles", "pmc_traffic.json")))
             if pmc.get("level") == args.level:
                 scale = in_bytes_rank / pmc["input_bytes"]
-                line["roofline"]["traffic"] = round((pmc["fetch_kb"] + pmc["write_kb"]) * 1024 * scale)
+                line["roofline"]["traffic"] = round((pmc["fetch_kb"] * pmc.get("fetch_scale", 1.0) + pmc["write_kb"]) * 1024 * scale)
                 line["roofline"]["traffic_note"] = pmc["note"]
         except Exception:
             pass
