@@ -220,6 +220,7 @@ DEV void sg_phase_begin(const LzJob &job, SgLds *lds, int w)
         LANEVAR(uint32_t, _q);                                                                \
         LANEVAR(uint32_t, _w0);                                                               \
         LANEVAR(int, _alive);                                                                 \
+        LANEVAR(int, _dead);                                                                  \
         LANEVAR(int, _pass);                                                                  \
         LANEVAR(int, _maybe);                                                                 \
         FOR_LANES                                                                             \
@@ -228,8 +229,9 @@ DEV void sg_phase_begin(const LzJob &job, SgLds *lds, int w)
             const uint32_t q = tileA + (LV(E) & ZD_TILE_MASK) - (_v < nA ? 0u : ZD_TILE);     \
             LV(_q) = q;                                                                       \
             LV(_alive) = _v == 0 || (_v < total && q > floor_pos); /* :1519 */                \
+            LV(_dead) = _v != 0 && _v < total && q <= floor_pos;                              \
         }                                                                                     \
-        const uint64_t _m_alive = BALLOT(_alive);                                             \
+        const uint64_t _m_dead = BALLOT(_dead);                                               \
         SG_COUNT(0, 1);                                                                       \
         FOR_LANES                                                                             \
         {                                                                                     \
@@ -292,12 +294,8 @@ DEV void sg_phase_begin(const LzJob &job, SgLds *lds, int w)
                 _todo &= ~((2ull << _j) - 1ull);                                              \
             }                                                                                 \
         }                                                                                     \
-        if (!fin) {                                                                           \
-            const uint32_t _left = total - (B)*64u;                                           \
-            const uint64_t _valid = _left >= 64u ? ~0ull : ((1ull << _left) - 1ull);          \
-            if (_m_alive != _valid)                                                           \
-                fin = 1; /* the chain leaves the window (:1519) */                            \
-        }                                                                                     \
+        if (_m_dead != 0 && !fin)                                                             \
+            fin = 1; /* the chain leaves the window (:1519) */                                \
     } while (0)
 
 /* four window positions at once: which of the 16-bit strings at byte offsets 0..3 of the
@@ -439,8 +437,11 @@ DEV void sg_parse_segment(const LzJob &job, SgLds *lds, const SgScratch &scr, ui
     LANEVAR(uint32_t, stg);
     LANEVAR(uint32_t, sdx);
     FOR_LANES { LV(mrk) = LV(mcn) = LV(pw) = LV(pv) = LV(stg) = LV(sdx) = 0; }
-    uint32_t mt_at = 0, pw_at = 0, pv_at = 0xffffffffu;
-    int mt_valid = 0, pw_valid = 0;
+    /* the two caches start out of range of p, so that their one range test fails */
+    uint32_t mt_at = p + 4096u, pw_at = p + 4096u, pv_at = 0xffffffffu;
+    uint32_t lit = 0;                      /* the byte at p-1 */
+    if (pending)
+        lit = UNI(lds->ring[lz_ridx<L>(st, p - 1u)]);
     uint32_t tw = 0, tw_idx = 0xffffffffu; /* trace word being filled */
     uint32_t sd_blk = 0xffffffffu;         /* 64-position block sdx belongs to */
 
@@ -454,7 +455,7 @@ DEV void sg_parse_segment(const LzJob &job, SgLds *lds, const SgScratch &scr, ui
                 break;
             }
         }
-        const int fresh = !pending && cur_len == 2;
+        const int fresh = ((uint32_t)pending | (cur_len ^ 2u)) == 0;
         if (p >= e_s) {
             if (p >= E) {
                 exit_kind = SG_EXIT_LAST;
@@ -472,7 +473,7 @@ DEV void sg_parse_segment(const LzJob &job, SgLds *lds, const SgScratch &scr, ui
                 exit_kind = SG_EXIT_UNSYNCED;
                 break;
             }
-        } else if (fresh && p >= a_s) {
+        } else if (fresh) { /* p >= a_s always: every parser starts inside its segment */
             const uint32_t r = p - a_s;
             if ((r >> 5) != tw_idx) {
                 if (tw_idx != 0xffffffffu) {
@@ -494,19 +495,19 @@ DEV void sg_parse_segment(const LzJob &job, SgLds *lds, const SgScratch &scr, ui
                     LV(sdx) = ntok;
             }
         }
-        if (!pw_valid || p < pw_at + 1u || p - pw_at > 224u) {
-            pw_valid = 1;
+        if (p - 1u - pw_at > 223u) { /* p-1 .. p+24 must lie inside the copy */
             pw_at = p & ~3u;
             if (pw_at >= 4u)
                 pw_at -= 4u;
             FOR_LANES { LV(pw) = ld_u32(&lds->ring[lz_ridx<L>(st, pw_at + 4u * (uint32_t)LANE)]); }
         }
 
+        uint32_t s0123;
+        SG_PEEK32(p, s0123);
         const uint32_t prev_len = cur_len, prev_at = cur_at;
         cur_len = 2;
         if (look >= 3 && prev_len < job.cfg.lazy) {
-            if (!mt_valid || p - mt_at >= WAVE) {
-                mt_valid = 1;
+            if (p - mt_at >= WAVE) {
                 mt_at = p;
                 FOR_LANES
                 {
@@ -525,10 +526,9 @@ DEV void sg_parse_segment(const LzJob &job, SgLds *lds, const SgScratch &scr, ui
                 const uint32_t floor_pos = p - st.base > ZD_MAX_DIST ? p - ZD_MAX_DIST : st.base;
                 const uint32_t cap = look < 258u ? look : 258u;
                 const uint32_t nice = job.cfg.nice < look ? job.cfg.nice : look;
-                uint32_t best = prev_len, where = cur_at, sb = 0, s0123;
+                uint32_t best = prev_len, where = cur_at, sb = 0;
                 uint32_t budget = prev_len >= job.cfg.good ? job.cfg.chain >> 2 : job.cfg.chain;
                 int fin = 0, head_seen = 0;
-                SG_PEEK32(p, s0123);
                 LANEVAR(uint32_t, e0);
                 LANEVAR(uint32_t, e1);
                 LANEVAR(uint32_t, e2);
@@ -555,9 +555,15 @@ DEV void sg_parse_segment(const LzJob &job, SgLds *lds, const SgScratch &scr, ui
                     SG_PEEK32(p + best - 1, sb);
                     sb &= 0xffffu;
                 }
-                if (!fin && q0 > floor_pos && total > 128u * ((q0 - floor_pos) / 1024u + 2u)) {
+                int sweep = 0;
+                if (total > 256u) {
+                    if (q0 > floor_pos)
+                        sweep = total > 128u * ((q0 - floor_pos) / 1024u + 2u);
+                }
+                if (fin) {
+                } else if (sweep) {
                     SG_SWEEP(q0);
-                } else if (!fin) {
+                } else {
                     for (uint32_t b0 = 0;; b0 += 4u) {
                         const int more = (b0 + 4u) * 64u < total;
                         if (more) {
@@ -585,12 +591,17 @@ DEV void sg_parse_segment(const LzJob &job, SgLds *lds, const SgScratch &scr, ui
                         }
                     }
                 }
-                if (fin != 2 && head_seen) {
+                if (head_seen) {
                     cur_at = where;
                     cur_len = best < look ? best : look;
-                    if (cur_len <= 5 &&
-                        (job.strategy == 1 || (cur_len == 3 && p - cur_at > ZD_TOO_FAR)))
-                        cur_len = 2;
+                    if (cur_len <= 5) { /* :2038-2047 */
+                        if (job.strategy == 1)
+                            cur_len = 2;
+                        else if (cur_len == 3) {
+                            if (p - cur_at > ZD_TOO_FAR)
+                                cur_len = 2;
+                        }
+                    }
                 }
             }
         }
@@ -603,14 +614,14 @@ DEV void sg_parse_segment(const LzJob &job, SgLds *lds, const SgScratch &scr, ui
             cur_len = 2;
             p += prev_len - 1;
         } else if (pending) {
-            SG_PEEK32(p - 1, sym);
-            sym &= 0xffu;
+            sym = lit;
             emit = 1;
             p++;
         } else {
             pending = 1;
             p++;
         }
+        lit = s0123 & 0xffu; /* the byte a literal emitted by the next iteration stands for */
         if (emit) {
             FOR_LANES
             {
