@@ -45,7 +45,9 @@
 #ifndef SG_G
 #define SG_G 256u                   /* positions per segment */
 #endif
+#ifndef SG_SPAN
 #define SG_SPAN 8192u               /* positions per super-step */
+#endif
 #define SG_NS (SG_SPAN / SG_G)      /* segments per super-step, handed to the waves by a work queue */
 #define SG_OV 512u                  /* how far past its segment a parser looks for a hand-over */
 #define SG_TRACE SG_G               /* positions a segment records (its own) */
@@ -63,7 +65,10 @@ typedef struct {
 } SgWave;
 
 struct SgLds {
-    static constexpr uint32_t RING = 45056u, CHUNK = 2048u;
+    /* window (32 KiB back) + one super-step + overlap + two lookaheads + one chunk being
+     * loaded, in whole chunks: 45056 for the default super-step */
+    static constexpr uint32_t CHUNK = 2048u;
+    static constexpr uint32_t RING = (ZD_TILE + SG_SPAN + SG_OV + 2u * ZD_MIN_LOOKAHEAD + 2u * CHUNK - 1u) / CHUNK * CHUNK;
     static constexpr bool HAS_INS = false;
     uint8_t ring[RING + 512];
     uint32_t trace[SG_NS][SG_TRACE / 32];
