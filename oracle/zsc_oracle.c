@@ -1110,6 +1110,7 @@ static int zo_decode(zo_reader *r, const zo_code *c)
         /* a table of invalid-code markers with bits = 1 (src/inftrees.c:150-158) */
         if (!zo_want(r, 1))
             return -1;
+        (void)zo_take(r, 1); /* DROPBITS(here.bits) comes before the op test, src/inflate.c:1217-1236 */
         return -2;
     }
     uint32_t code = 0, first = 0, index = 0;
@@ -1137,6 +1138,23 @@ static const uint16_t zo_inf_lbase[29] = {3,  4,  5,  6,  7,  8,  9,  10, 11,  1
 static const uint16_t zo_inf_dbase[30] = {1,   2,   3,   4,   5,   7,    9,    13,   17,   25,
                                           33,  49,  65,  97,  129, 193,  257,  385,  513,  769,
                                           1025, 1537, 2049, 3073, 4097, 6145, 8193, 12289, 16385, 24577};
+
+/* syncsearch, src/inflate.c:1523-1545: advance the 00 00 FF FF matcher over buf */
+static uint32_t zo_syncsearch(uint32_t *have, const uint8_t *buf, uint32_t len)
+{
+    uint32_t got = *have, next = 0;
+    while (next < len && got < 4) {
+        if (buf[next] == (got < 2 ? 0 : 0xff))
+            got++;
+        else if (buf[next])
+            got = 0;
+        else
+            got = 4 - got;
+        next++;
+    }
+    *have = got;
+    return next;
+}
 
 int zo_uncompress(uint8_t *dest, uint32_t *dest_len, const uint8_t *source, uint32_t *source_len,
                   uint32_t work_len, int window_bits)
@@ -1167,6 +1185,9 @@ int zo_uncompress(uint8_t *dest, uint32_t *dest_len, const uint8_t *source, uint
 
     zo_reader r = {source, avail, 0, 0, 0};
     uint32_t out = 0, dmax = 32768u;
+    int data_errors = 0;
+    uint32_t out_base = 0; /* output of the current inflate() call starts here: nothing before it
+                              can be copied from once inflateSync has reset the window */
     int gzip = 0, rc = ZO_OK;
 
 #define ZO_NEED(nb)          \
@@ -1174,11 +1195,11 @@ int zo_uncompress(uint8_t *dest, uint32_t *dest_len, const uint8_t *source, uint
         rc = ZO_BUF_ERROR;    \
         goto done;            \
     }
-#define ZO_BAD             \
-    {                      \
-        rc = ZO_DATA_ERROR; \
-        goto done;         \
-    }
+/* A data error.  At every such point the bit buffer holds exactly what the reference's
+ * `hold`/`bits` hold there (bytes are pulled one at a time as NEEDBITS does, and a field is
+ * only taken out of the buffer where the reference drops it), because inflateSync starts
+ * its search in those buffered bits (src/inflate.c:1570-1582). */
+#define ZO_BAD goto bad;
 
     /* HEAD .. HCRC, src/inflate.c:740-954 */
     if (wrap) {
@@ -1188,11 +1209,12 @@ int zo_uncompress(uint8_t *dest, uint32_t *dest_len, const uint8_t *source, uint
             gzip = 1;
             (void)zo_take(&r, 16);
             ZO_NEED(16);
-            uint32_t flags = zo_take(&r, 16);
+            uint32_t flags = (uint32_t)(r.acc & 0xffff);
             if ((flags & 0xff) != 8)
                 ZO_BAD;
             if (flags & 0xe000)
                 ZO_BAD;
+            (void)zo_take(&r, 16); /* INITBITS, :779 */
             ZO_NEED(32);
             (void)zo_take(&r, 32); /* mtime */
             ZO_NEED(16);
@@ -1231,15 +1253,17 @@ int zo_uncompress(uint8_t *dest, uint32_t *dest_len, const uint8_t *source, uint
             if (flags & 0x0200) {
                 uint32_t upto = r.pos;
                 ZO_NEED(16);
-                uint32_t got = zo_take(&r, 16);
+                uint32_t got = (uint32_t)(r.acc & 0xffff);
                 if (want_crc && got != (zo_crc32(0, source, upto) & 0xffff))
                     ZO_BAD;
+                (void)zo_take(&r, 16);
             }
         } else {
             if (!(wrap & 1) || ((((hw & 0xff) << 8) + (hw >> 8)) % 31))
                 ZO_BAD;
             if ((hw & 0xf) != 8)
                 ZO_BAD;
+            (void)zo_take(&r, 4); /* DROPBITS(4), :757 */
             uint32_t len = ((hw >> 4) & 0xf) + 8;
             uint32_t wbits_eff = wb ? (uint32_t)wb : len;
             if (len > 15 || len > wbits_eff)
@@ -1248,7 +1272,7 @@ int zo_uncompress(uint8_t *dest, uint32_t *dest_len, const uint8_t *source, uint
             if (hw & 0x2000) {
                 /* FDICT (bit 5 of FLG = bit 13 here): Z_NEED_DICT = 2 in the reference; the
                  * one-shot wrapper then fails with that code (src/zsc_uncompr.c:132-140) */
-                (void)zo_take(&r, 16);
+                (void)zo_take(&r, 12);
                 ZO_NEED(32);
                 (void)zo_take(&r, 32);
                 /* the DICT state returns straight out of inflate() without the exit
@@ -1257,11 +1281,12 @@ int zo_uncompress(uint8_t *dest, uint32_t *dest_len, const uint8_t *source, uint
                 *source_len = 0;
                 return 2;
             }
-            (void)zo_take(&r, 16);
+            (void)zo_take(&r, 12);
         }
     }
 
     /* TYPE .. MATCH, src/inflate.c:975-1321 and src/inffast.c:125-297 */
+blocks:
     for (;;) {
         ZO_NEED(3);
         uint32_t last = zo_take(&r, 1);
@@ -1271,9 +1296,10 @@ int zo_uncompress(uint8_t *dest, uint32_t *dest_len, const uint8_t *source, uint
         if (type == 0) {
             (void)zo_take(&r, r.fill & 7);
             ZO_NEED(32);
-            uint32_t v = zo_take(&r, 32);
+            uint32_t v = (uint32_t)(r.acc & 0xffffffffu);
             if ((v & 0xffff) != ((v >> 16) ^ 0xffff))
                 ZO_BAD;
+            (void)zo_take(&r, 32);
             uint32_t len = v & 0xffff;
             /* the bit buffer is empty here (INITBITS, :1019) */
             while (len) {
@@ -1323,7 +1349,9 @@ int zo_uncompress(uint8_t *dest, uint32_t *dest_len, const uint8_t *source, uint
                         goto done;
                     }
                     if (sym == -2)
-                        ZO_BAD; /* unreachable for a complete code; kept for safety */
+                        sym = 0; /* an all-zero code-length code: the CODELENS state never looks at
+                                    the invalid-code marker's op, only at its val 0 and bits 1
+                                    (src/inflate.c:1105-1114, src/inftrees.c:150-158) */
                     if (sym < 16) {
                         lens[have++] = (uint16_t)sym;
                         continue;
@@ -1387,7 +1415,13 @@ int zo_uncompress(uint8_t *dest, uint32_t *dest_len, const uint8_t *source, uint
                 eb = zo_dist_extra[ds];
                 ZO_NEED(eb);
                 uint32_t dist = zo_inf_dbase[ds] + zo_take(&r, eb);
-                if (dist > dmax || dist > out)
+                if (dist > dmax) /* DISTEXT, :1266-1272 */
+                    ZO_BAD;
+                if (out >= cap) { /* MATCH leaves on a full output before it looks at the distance (:1277) */
+                    rc = ZO_BUF_ERROR;
+                    goto done;
+                }
+                if (dist > out - out_base) /* :1279-1288 */
                     ZO_BAD;
                 while (len--) {
                     if (out >= cap) {
@@ -1407,20 +1441,58 @@ int zo_uncompress(uint8_t *dest, uint32_t *dest_len, const uint8_t *source, uint
     (void)zo_take(&r, r.fill & 7);
     if (wrap) {
         ZO_NEED(32);
-        uint32_t v = zo_take(&r, 32);
+        uint32_t v = (uint32_t)(r.acc & 0xffffffffu);
         if (wrap & 4) {
+            /* state->check runs on across an inflateSync: it covers everything written */
             uint32_t want = gzip ? zo_crc32(0, dest, out) : zo_adler32(1, dest, out);
             uint32_t got = gzip ? v : ((v >> 24) | ((v >> 8) & 0xff00) | ((v & 0xff00) << 8) | (v << 24));
             if (got != want)
                 ZO_BAD;
         }
+        (void)zo_take(&r, 32);
         if (gzip) {
             ZO_NEED(32);
-            if (zo_take(&r, 32) != out)
+            /* state->total restarts at an inflateSync (inflateResetKeep, :288) */
+            if ((uint32_t)(r.acc & 0xffffffffu) != out - out_base)
                 ZO_BAD;
+            (void)zo_take(&r, 32);
         }
     }
     rc = 1; /* Z_STREAM_END */
+    goto done;
+
+bad:
+    /* zsc_uncompress answers Z_DATA_ERROR with inflateSync (src/zsc_uncompr.c:109-125,
+     * src/inflate.c:1547-1604): look for the next 00 00 FF FF -- the empty stored block a
+     * full flush leaves between sections -- first in the buffered bits, then in the input,
+     * and decode on from there as a raw stream with an empty window. */
+    data_errors++;
+    if (r.pos >= r.n && r.fill < 8) { /* :1562-1565 */
+        rc = ZO_BUF_ERROR;
+        goto done;
+    }
+    {
+        uint32_t hold = (uint32_t)r.acc, bits = r.fill, have = 0, len = 0;
+        uint8_t buf[4];
+        hold <<= bits & 7; /* sic, :1571 */
+        bits -= bits & 7;
+        while (bits >= 8) {
+            buf[len++] = (uint8_t)hold;
+            hold >>= 8;
+            bits -= 8;
+        }
+        (void)zo_syncsearch(&have, buf, len);
+        r.pos += zo_syncsearch(&have, source + r.pos, r.n - r.pos);
+        r.acc = 0; /* inflateReset */
+        r.fill = 0;
+        if (have != 4) {
+            rc = ZO_DATA_ERROR;
+            goto done;
+        }
+        out_base = out; /* whave = 0: copies cannot reach behind this call's output */
+        dmax = 32768u;
+        goto blocks; /* mode = TYPE */
+    }
 
 done:
 #undef ZO_NEED
@@ -1429,8 +1501,8 @@ done:
     /* bytes are pulled into the bit buffer only on demand, as in the reference's
      * NEEDBITS/PULLBYTE states, so everything pulled counts as consumed */
     *source_len = r.pos;
-    if (rc == 1)
-        return ZO_OK;
+    if (rc == 1) /* a stream that ended well after a resynchronisation still reports the error (:149-152) */
+        return data_errors ? ZO_DATA_ERROR : ZO_OK;
     /* src/zsc_uncompr.c:132-141: Z_OK would become Z_STREAM_ERROR; inflate(Z_FINISH)
      * reports an unfinished stream as Z_BUF_ERROR (src/inflate.c:1400-1402) */
     return rc;

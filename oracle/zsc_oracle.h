@@ -81,9 +81,9 @@ int zo_compress(uint8_t *dest, uint32_t *dest_len, const uint8_t *source, uint32
                 int mem_level, int strategy, int *unsupported);
 
 /* whole call: semantics of reference zsc_uncompress_gzip2 (src/zsc_uncompr.c:44-154)
- * with gz_head == NULL, for streams that decode without a data error. On a data
- * error returns ZO_DATA_ERROR with the bytes produced before the error (the
- * reference's inflateSync resynchronisation is not restated: SURVEY.md 8f-2). */
+ * with gz_head == NULL, including what it does after a data error: inflateSync looks for
+ * the next full-flush marker and decoding goes on from there (src/inflate.c:1523-1604);
+ * the call then ends in ZO_DATA_ERROR or ZO_BUF_ERROR with everything salvaged in dest. */
 int zo_uncompress(uint8_t *dest, uint32_t *dest_len, const uint8_t *source,
                   uint32_t *source_len, uint32_t work_len, int window_bits);
 

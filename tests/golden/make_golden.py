@@ -23,6 +23,22 @@ from zsc_amd import corpus  # noqa: E402
 HERE = os.path.dirname(os.path.abspath(__file__))
 
 
+def apply_edits(stream: bytes, ops) -> bytes:
+    """["f", pos, mask] xor a byte, ["x", pos, hex] overwrite, ["d", pos, count] delete, ["t", len] truncate"""
+    b = bytearray(stream)
+    for op in ops:
+        if op[0] == "f":
+            b[op[1]] ^= op[2]
+        elif op[0] == "x":
+            raw = bytes.fromhex(op[2])
+            b[op[1]:op[1] + len(raw)] = raw
+        elif op[0] == "d":
+            del b[op[1]:op[1] + op[2]]
+        else:
+            del b[op[1]:]
+    return bytes(b)
+
+
 def sha(b: bytes) -> str:
     return hashlib.sha256(b).hexdigest()
 
@@ -139,14 +155,56 @@ def main():
         bad[pos] = (bad[pos] + 1) & 0xff
         rc, out, used = R.uncompress(bytes(bad), len(src), 15)
         corrupt.append({"flip": pos, "rc": rc, "out_len": len(out), "consumed": used,
-                        "prefix_ok": src.startswith(out[:64])})
+                        "out_sha256": sha(out)})
     for cut in (1, 2, 7, len(good) // 2, len(good) - 4, len(good) - 1):
         rc, out, used = R.uncompress(good[:cut], len(src), 15)
         corrupt.append({"cut": cut, "rc": rc, "out_len": len(out), "consumed": used,
                         "out_sha256": sha(out)})
+    # streams with full-flush markers between sections (the reference's own multi-section
+    # output), damaged in seeded ways: what zsc_uncompress recovers after inflateSync
+    import random
+    rnd = random.Random(20)
+    resync = []
+    for kind, n, mbl, wb, lvl in (("text", 6000, 1000, 15, 6), ("zero", 5000, 700, 15, 6),
+                                  ("table", 8000, 1500, 31, 9), ("runs", 4000, 512, -15, 1),
+                                  ("object", 7000, 2000, 31, 6), ("bitmap", 9000, 3000, 15, 4)):
+        data = corpus.make_buffer(kind, n, 77)
+        rc, comp = R.compress(data, lvl, window_bits=wb, max_block_len=mbl, dest_cap=2 * n + 1000)
+        assert rc == 0 and comp.count(b"\x00\x00\xff\xff") >= 1
+        cases = []
+        for k in range(28):
+            ops = []  # edits applied in order: ["x", pos, hex] overwrite, ["d", pos, count] delete, ["t", len] truncate
+            ln = len(comp)
+            mode = k % 6
+            if mode == 0:
+                for _ in range(rnd.randrange(1, 4)):
+                    i = rnd.randrange(ln)
+                    ops.append(["f", i, 1 << rnd.randrange(8)])
+            elif mode == 1:
+                ops.append(["x", rnd.randrange(ln), "%02x" % rnd.randrange(256)])
+            elif mode == 2:
+                i = rnd.randrange(ln)
+                j = min(ln, i + rnd.randrange(1, 40))
+                ops.append(["x", i, bytes(rnd.randrange(256) for _ in range(j - i)).hex()])
+            elif mode == 3:
+                ops.append(["d", rnd.randrange(ln), rnd.randrange(1, 20)])
+            elif mode == 4:
+                ln = rnd.randrange(1, ln + 1)
+                ops.append(["t", ln])
+                if ln > 4:
+                    ops.append(["f", rnd.randrange(ln), 0x55])
+            else:
+                ops.append(["f", rnd.randrange(min(ln, 12)), 1 << rnd.randrange(8)])
+            b = apply_edits(comp, ops)
+            cap = (n, n + 100, max(1, n // 2))[k % 3]
+            rc, out, used = R.uncompress(bytes(b), cap, wb)
+            cases.append({"edits": ops, "dest_cap": cap, "rc": rc, "out_len": len(out),
+                          "consumed": used, "out_sha256": sha(out)})
+        resync.append({"kind": kind, "size": n, "seed": 77, "window_bits": wb, "stream_hex": comp.hex(),
+                       "cases": cases})
     json.dump({"deflate": deflate_cases, "streams": streams, "params": params, "small": small,
                "sections": sections}, open(os.path.join(HERE, "deflate_golden.json"), "w"), indent=0)
-    json.dump({"checksums": sums, "inflate_kat": kats, "corrupt": corrupt,
+    json.dump({"checksums": sums, "inflate_kat": kats, "corrupt": corrupt, "resync": resync,
                "corrupt_source": {"kind": "text", "size": 20000, "seed": 3, "level": 6}},
               open(os.path.join(HERE, "inflate_golden.json"), "w"), indent=0)
     print(len(deflate_cases), "deflate cases,", len(kats), "inflate KATs")
