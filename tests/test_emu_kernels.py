@@ -99,3 +99,46 @@ def test_segmented_parser_hand_over_orders(emu, oracle):
                         assert rc == orc == 0 and got == want, (mode, n, kind, level)
     finally:
         emu.emu_set_seg_mode(0)
+
+
+def emu_uncompress(L, data, cap, wb):
+    dst = C.create_string_buffer(max(cap, 1))
+    ol, used = C.c_uint32(), C.c_uint32()
+    rc = L.emu_uncompress(data, len(data), wb, dst, cap, C.byref(ol), C.byref(used))
+    return rc, dst.raw[:ol.value], used.value
+
+
+def test_inflate_kernel_including_resynchronisation(emu, oracle):
+    """inflate.h lane by lane: the reference's known answers, round trips, and damaged
+    multi-section streams (inflateSync recovery) from the golden fixtures, against the
+    recorded outcome of the reference and against the oracle."""
+    import hashlib
+    import json
+    from test_oracle import apply_edits
+    g = json.load(open(os.path.join(HERE, "golden", "inflate_golden.json")))
+    for c in g["inflate_kat"]:
+        raw = bytes(int(x, 16) for x in c["hex"].split())
+        rc, out, used = emu_uncompress(emu, raw, c["dest_cap"], c["window_bits"])
+        assert (rc, out.hex(), used) == (c["rc"], c["out_hex"], c["consumed"]), c
+    for r in g["resync"]:
+        stream = bytes.fromhex(r["stream_hex"])
+        data = corpus.make_buffer(r["kind"], r["size"], r["seed"])
+        assert emu_uncompress(emu, stream, len(data), r["window_bits"]) == (0, data, len(stream))
+        for c in r["cases"]:
+            rc, out, used = emu_uncompress(emu, apply_edits(stream, c["edits"]), c["dest_cap"], r["window_bits"])
+            assert (rc, len(out), used, hashlib.sha256(out).hexdigest()) == \
+                   (c["rc"], c["out_len"], c["consumed"], c["out_sha256"]), c
+    # seeded damage to single-section streams of every wrapper: kernel == oracle
+    import random
+    rnd = random.Random(9)
+    for i in range(300):
+        n = rnd.choice([200, 3000, 20000])
+        data = corpus.make_buffer(("text", "zero", "table", "random", "runs")[i % 5], n, i)
+        wb = (15, 31, -15)[i % 3]
+        comp = bytearray(oracle.compress(data, (1, 6, 9)[i % 3], window_bits=wb)[1])
+        for _ in range(rnd.randrange(1, 3)):
+            comp[rnd.randrange(len(comp))] ^= 1 << rnd.randrange(8)
+        if i % 7 == 0:
+            del comp[rnd.randrange(len(comp)):]
+        cap = rnd.choice([n, n + 50, max(1, n // 2)])
+        assert emu_uncompress(emu, bytes(comp), cap, wb) == oracle.uncompress(bytes(comp), cap, wb), (i, wb, cap)

@@ -172,6 +172,10 @@ DEV void inflate_stream(const InfJob &job, InfLds *lds, InfResult *res)
     int gzip = 0;
     int rc = INF_OK;
     int exhausted = 0; /* ran out of input */
+    uint32_t data_errors = 0; /* data errors survived by resynchronising (zsc_uncompress's loop) */
+    uint32_t out_base = 0;    /* output of the current inflate() call starts here */
+    uint64_t sy_start = 0;    /* at a data error: where the reference's bit buffer starts (bit offset) */
+    uint32_t sy_rb = 0;       /* ... and how many bits it holds */
     uint32_t fail_line = 0; /* source line of the check that rejected the stream (diagnostics) */
 
 /* top up the bit buffer to at least 32 bits (or to the end of the input) */
@@ -235,11 +239,41 @@ DEV void inflate_stream(const InfJob &job, InfLds *lds, InfResult *res)
         br.used += _nb;                                            \
     } while (0)
 
-#define INF_BAD              \
-    do {                     \
-        rc = INF_DATA;       \
-        fail_line = __LINE__; \
-        goto done;           \
+/* A data error.  inflateSync starts its search in the bits the reference has buffered at
+ * that point (src/inflate.c:1570-1582), so every error site states them: BACK bits already
+ * taken here that the reference has not dropped yet, RB bits in its `hold` in all.  The
+ * usual case is "whatever is left of the current byte". */
+#define INF_BADX(BACK, RB)                                  \
+    do {                                                    \
+        sy_start = br.used - (uint64_t)(int64_t)(BACK);     \
+        sy_rb = (uint32_t)(RB);                             \
+        fail_line = __LINE__;                               \
+        goto bad;                                           \
+    } while (0)
+#define INF_BAD INF_BADX(0, (8u - (uint32_t)(br.used & 7u)) & 7u)
+
+/* put the bit reader at byte P of the input */
+#define INF_SEEK(P)                                                                           \
+    do {                                                                                      \
+        br.used = (uint64_t)(P)*8u;                                                           \
+        br.hold = 0;                                                                          \
+        br.bits = 0;                                                                          \
+        br.next = (P);                                                                        \
+        if (br.next - br.chunk_at >= 256u || br.next < br.chunk_at) {                         \
+            br.chunk_at = br.next & ~255u;                                                    \
+            FOR_LANES                                                                         \
+            {                                                                                 \
+                uint32_t _a = br.chunk_at + 4u * (uint32_t)LANE;                              \
+                uint32_t _w = 0;                                                              \
+                if (_a + 4 <= n)                                                              \
+                    _w = ld_u32(src + _a);                                                    \
+                else                                                                          \
+                    for (uint32_t _j = 0; _j < 4; _j++)                                       \
+                        if (_a + _j < n)                                                      \
+                            _w |= (uint32_t)src[_a + _j] << (8 * _j);                         \
+                LV(cur) = _w;                                                                 \
+            }                                                                                 \
+        }                                                                                     \
     } while (0)
 
 /* store the completed 256-byte pieces of the staging area */
@@ -265,6 +299,9 @@ DEV void inflate_stream(const InfJob &job, InfLds *lds, InfResult *res)
         if ((C)->empty) {                                                                     \
             /* a table of invalid-code markers of length 1 (src/inftrees.c:150-158) */        \
             INF_NEED(1);                                                                      \
+            uint32_t _d1;                                                                     \
+            INF_TAKE(_d1, 1); /* DROPBITS(here.bits) precedes the op test, :1217-1236 */      \
+            (void)_d1;                                                                        \
             (OUTSYM) = -2;                                                                       \
             break;                                                                            \
         }                                                                                     \
@@ -321,7 +358,7 @@ DEV void inflate_stream(const InfJob &job, InfLds *lds, InfResult *res)
             INF_NEED(16);
             INF_TAKE(flags, 16);
             if ((flags & 0xff) != 8 || (flags & 0xe000))
-                INF_BAD;
+                INF_BADX(16, 16); /* the flags word is still in hold, :771-779 */
             INF_NEED(32);
             INF_TAKE(t, 32);
             INF_NEED(16);
@@ -353,19 +390,19 @@ DEV void inflate_stream(const InfJob &job, InfLds *lds, InfResult *res)
                 INF_NEED(16);
                 INF_TAKE(got, 16);
                 if ((wrap & 4) && got != (ck_crc32(src, upto, &lds->ck) & 0xffffu))
-                    INF_BAD;
+                    INF_BADX(16, 16); /* :944-950 */
             }
         } else {
             uint32_t t = 0;
             (void)t;
             if (!(wrap & 1) || ((((hw & 0xff) << 8) + (hw >> 8)) % 31u))
-                INF_BAD;
+                INF_BADX(0, 16); /* nothing dropped yet, :746-756 */
             if ((hw & 0xf) != 8)
-                INF_BAD;
+                INF_BADX(0, 16);
             const uint32_t len = ((hw >> 4) & 0xf) + 8;
             const uint32_t wbits_eff = wb ? (uint32_t)wb : len;
             if (len > 15 || len > wbits_eff)
-                INF_BAD;
+                INF_BADX(-4, 12); /* after DROPBITS(4), :757-764 */
             dmax = 1u << len;
             INF_TAKE(t, 16);
             if (hw & 0x2000) {
@@ -380,6 +417,7 @@ DEV void inflate_stream(const InfJob &job, InfLds *lds, InfResult *res)
     }
 
     /* blocks */
+blocks:
     for (;;) {
         uint32_t last, type;
         INF_NEED(3);
@@ -394,7 +432,7 @@ DEV void inflate_stream(const InfJob &job, InfLds *lds, InfResult *res)
             INF_NEED(32);
             INF_TAKE(v, 32);
             if ((v & 0xffff) != ((v >> 16) ^ 0xffff))
-                INF_BAD;
+                INF_BADX(32, 32); /* LEN/NLEN still in hold, :1011-1016 */
             uint32_t len = v & 0xffff;
             /* the remaining bytes of the bit buffer belong to the stored data */
             const uint32_t at = (uint32_t)(br.used >> 3); /* input offset of the first data byte */
@@ -420,26 +458,7 @@ DEV void inflate_stream(const InfJob &job, InfLds *lds, InfResult *res)
                 pos += step;
                 INF_FLUSH(0);
             }
-            br.used = ((uint64_t)at + can) * 8u;
-            br.hold = 0;
-            br.bits = 0;
-            br.next = at + can;
-            if (br.next - br.chunk_at >= 256u || br.next < br.chunk_at) {
-                /* re-seat the input chunk at the new position */
-                br.chunk_at = br.next & ~255u;
-                FOR_LANES
-                {
-                    uint32_t a = br.chunk_at + 4u * (uint32_t)LANE;
-                    uint32_t w = 0;
-                    if (a + 4 <= n)
-                        w = ld_u32(src + a);
-                    else
-                        for (uint32_t j = 0; j < 4; j++)
-                            if (a + j < n)
-                                w |= (uint32_t)src[a + j] << (8 * j);
-                    LV(cur) = w;
-                }
-            }
+            INF_SEEK(at + can);
             if (short_in || short_out) {
                 rc = INF_BUF; /* COPY state leaves with nothing more to do, src/inflate.c:1037-1039 */
                 goto done;
@@ -492,7 +511,7 @@ DEV void inflate_stream(const InfJob &job, InfLds *lds, InfResult *res)
                     int sym;
                     INF_DECODE(&lds->cl, sym);
                     if (sym < 0)
-                        INF_BAD;
+                        sym = 0; /* all-zero code-length code: CODELENS reads the marker's val 0, bits 1 (:1105-1114) */
                     if (sym < 16) {
                         ON_LANE0 { lds->lens[have] = (uint16_t)sym; }
                         WAVE_SYNC();
@@ -502,8 +521,11 @@ DEV void inflate_stream(const InfJob &job, InfLds *lds, InfResult *res)
                     uint32_t rep, val = 0;
                     if (sym == 16) {
                         INF_NEED(2);
-                        if (have == 0)
-                            INF_BAD;
+                        if (have == 0) {
+                            /* NEEDBITS(here.bits + 2) may have pulled one byte more (:1116-1123) */
+                            const uint32_t padb = (8u - (uint32_t)(br.used & 7u)) & 7u;
+                            INF_BADX(0, padb >= 2u ? padb : padb + 8u);
+                        }
                         val = lds->lens[have - 1];
                         INF_TAKE(rep, 2);
                         rep += 3;
@@ -568,7 +590,13 @@ DEV void inflate_stream(const InfJob &job, InfLds *lds, InfResult *res)
                 INF_NEED(xb);
                 INF_TAKE(ex, xb);
                 const uint32_t dist = (ds < 4 ? (uint32_t)ds : (2u + ((uint32_t)ds & 1u)) << (((uint32_t)ds >> 1) - 1u)) + 1u + ex;
-                if (dist > dmax || dist > pos)
+                if (dist > dmax) /* DISTEXT, :1266-1272 */
+                    INF_BAD;
+                if (pos >= cap) { /* MATCH leaves on a full output before it looks at the distance (:1277) */
+                    rc = INF_BUF;
+                    goto done;
+                }
+                if (dist > pos - out_base) /* :1279-1288; nothing behind an inflateSync can be copied */
                     INF_BAD;
                 uint32_t can = len;
                 if (can > cap - pos)
@@ -619,16 +647,78 @@ DEV void inflate_stream(const InfJob &job, InfLds *lds, InfResult *res)
                 const uint32_t want = gzip ? ck_crc32(dst, pos, &lds->ck) : ck_adler32(dst, pos);
                 const uint32_t got = gzip ? v : ((v >> 24) | ((v >> 8) & 0xff00u) | ((v & 0xff00u) << 8) | (v << 24));
                 if (got != want)
-                    INF_BAD;
+                    INF_BADX(32, 32); /* :1333-1339 */
             }
             if (gzip) {
                 INF_NEED(32);
                 INF_TAKE(v, 32);
-                if (v != pos)
-                    INF_BAD;
+                if (v != pos - out_base) /* state->total restarts at an inflateSync */
+                    INF_BADX(32, 32); /* :1347-1351 */
             }
         }
-        rc = INF_END;
+        rc = data_errors ? INF_DATA : INF_END; /* src/zsc_uncompr.c:149-152 */
+        goto done;
+    }
+
+bad:
+    /* zsc_uncompress answers Z_DATA_ERROR with inflateSync (src/zsc_uncompr.c:109-125,
+     * src/inflate.c:1547-1604): find the next 00 00 FF FF -- first in what is left of the bit
+     * buffer, then in the input -- and decode on from there as a raw stream. */
+    data_errors++;
+    INF_FLUSH(1);
+    {
+        const uint32_t nin = (uint32_t)((sy_start + sy_rb) >> 3); /* the reference's next_in */
+        if (nin >= n && sy_rb < 8u) {                              /* :1562-1565 */
+            rc = INF_BUF;
+            INF_SEEK(n < nin ? n : nin);
+            goto done;
+        }
+        /* hold: sy_rb bits of the stream from bit sy_start, then "hold <<= bits & 7" (sic) */
+        uint32_t hold = 0;
+        for (uint32_t k = 0; k < sy_rb; k += 8u) {
+            const uint64_t bit = sy_start + k;
+            const uint32_t by = (uint32_t)(bit >> 3), sh = (uint32_t)(bit & 7u);
+            uint32_t two = UNI(src[by]);
+            if (sh && by + 1u < n)
+                two |= UNI(src[by + 1u]) << 8;
+            hold |= ((two >> sh) & 0xffu) << k;
+        }
+        if (sy_rb < 32u)
+            hold &= (1u << sy_rb) - 1u;
+        uint32_t rb = sy_rb;
+        hold <<= rb & 7u;
+        rb -= rb & 7u;
+        const uint32_t nh = rb >> 3; /* bytes of hold searched before the input */
+        /* first occurrence of the pattern in hold-bytes ++ input[nin..n) */
+        const uint32_t vlen = nh + (n - nin);
+        uint32_t found = 0xffffffffu;
+        for (uint32_t base = 0; base + 4u <= vlen && found == 0xffffffffu; base += WAVE) {
+            LANEVAR(int, _hit);
+            FOR_LANES
+            {
+                const uint32_t m = base + (uint32_t)LANE;
+                int ok = m + 4u <= vlen;
+                for (uint32_t j = 0; j < 4u && ok; j++) {
+                    const uint32_t i = m + j;
+                    const uint32_t c = i < nh ? (hold >> (8u * i)) & 0xffu : src[nin + (i - nh)];
+                    ok = c == (j < 2u ? 0u : 0xffu);
+                }
+                LV(_hit) = ok;
+            }
+            const uint64_t hm = BALLOT(_hit);
+            if (hm != 0)
+                found = base + (uint32_t)CTZ64(hm);
+        }
+        if (found == 0xffffffffu) {
+            rc = INF_DATA; /* the search used up all the input (:1585-1593) */
+            INF_SEEK(n);
+            goto done;
+        }
+        const uint32_t taken = found + 4u > nh ? found + 4u - nh : 0u; /* input bytes up to the end of the pattern */
+        INF_SEEK(nin + taken);
+        out_base = pos; /* inflateReset: empty window, mode = TYPE */
+        dmax = 32768u;
+        goto blocks;
     }
 
 done:
@@ -647,6 +737,8 @@ done:
 #undef INF_NEED
 #undef INF_TAKE
 #undef INF_BAD
+#undef INF_BADX
+#undef INF_SEEK
 #undef INF_FLUSH
 #undef INF_DECODE
 }
