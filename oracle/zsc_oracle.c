@@ -422,6 +422,61 @@ static void zo_parse_greedy(zo_parser *z)
     zo_cut_block(z, p, 1);
 }
 
+/* deflate_rle, src/deflate.c:2129-2204 (Z_RLE): only runs -- matches at distance 1 */
+static void zo_parse_rle(zo_parser *z)
+{
+    uint32_t p = 0;
+    for (;;) {
+        uint32_t look = z->data_end - p;
+        if (look <= 258) { /* :2141 */
+            zo_refill(z, p);
+            look = z->data_end - p;
+            if (look == 0)
+                break;
+        }
+        uint32_t len = 0;
+        if (look >= 3 && p > 0) { /* strstart > 0: only the very first byte has window index 0 */
+            uint8_t prev = z->in[p - 1];
+            if (z->in[p] == prev && z->in[p + 1] == prev && z->in[p + 2] == prev) {
+                /* the reference scans on into whatever lies behind the data and clamps to
+                 * the lookahead afterwards (:2166-2169): the run inside the data, at most 258 */
+                len = 3;
+                while (len < 258 && len < look && z->in[p + len] == prev)
+                    len++;
+            }
+        }
+        int full;
+        if (len >= 3) {
+            full = zo_put_match(z, 1, len);
+            p += len;
+        } else {
+            full = zo_put_literal(z, z->in[p]);
+            p++;
+        }
+        if (full)
+            zo_cut_block(z, p, 0);
+    }
+    zo_cut_block(z, p, 1);
+}
+
+/* deflate_huff, src/deflate.c:2210-2247 (Z_HUFFMAN_ONLY): every byte a literal */
+static void zo_parse_huff(zo_parser *z)
+{
+    uint32_t p = 0;
+    for (;;) {
+        if (z->data_end - p == 0) { /* :2218 */
+            zo_refill(z, p);
+            if (z->data_end - p == 0)
+                break;
+        }
+        int full = zo_put_literal(z, z->in[p]);
+        p++;
+        if (full)
+            zo_cut_block(z, p, 0);
+    }
+    zo_cut_block(z, p, 1);
+}
+
 int zo_parse(const uint8_t *in, uint32_t n, int level, int wbits, int mem_level, int strategy,
              zo_symbol *syms, uint32_t *nsyms, zo_block *blocks, uint32_t *nblocks)
 {
@@ -449,7 +504,11 @@ int zo_parse(const uint8_t *in, uint32_t n, int level, int wbits, int mem_level,
     }
     z.syms = syms;
     z.blocks = blocks;
-    if (z.cfg.slow)
+    if (strategy == 2) /* the strategy decides before the level does, src/deflate.c:1216-1219 */
+        zo_parse_huff(&z);
+    else if (strategy == 3)
+        zo_parse_rle(&z);
+    else if (z.cfg.slow)
         zo_parse_lazy(&z);
     else
         zo_parse_greedy(&z);
@@ -949,8 +1008,7 @@ int zo_compress(uint8_t *dest, uint32_t *dest_len, const uint8_t *source, uint32
     if (wb == 8)
         wb = 9;
 
-    if (max_block_len == 0 || source_len > max_block_len || level == 0 || strategy == 2 ||
-        strategy == 3) {
+    if (max_block_len == 0 || source_len > max_block_len || level == 0) {
         *unsupported = 1;
         return ZO_STREAM_ERROR;
     }

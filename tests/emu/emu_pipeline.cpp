@@ -35,6 +35,7 @@ static inline void sg_count(int what, unsigned n)
 }
 #define SG_COUNT(what, n) sg_count(what, n)
 #include "../../zsc_amd/csrc/lz_parse_seg.h"
+#include "../../zsc_amd/csrc/lz_parse_simple.h"
 #include "../../zsc_amd/csrc/huff_plan.h"
 #include "../../zsc_amd/csrc/bit_emit.h"
 #include "../../zsc_amd/csrc/checksum.h"
@@ -131,6 +132,16 @@ static void run_parse_seg(const LzJob &job, int order)
 
 static void run_parse(const LzJob &job)
 {
+    if (job.strategy == 2u || job.strategy == 3u) { /* Z_HUFFMAN_ONLY, Z_RLE */
+        SpLds *lds = (SpLds *)malloc(sizeof(SpLds));
+        memset(lds, 0x5D, sizeof(SpLds));
+        if (job.strategy == 2u)
+            lz_parse_huff(job, lds);
+        else
+            lz_parse_rle(job, lds);
+        free(lds);
+        return;
+    }
     if (job.cfg.slow && (g_seg_mode >= 2 || (g_seg_mode == 0 && job.n > 18432u))) {
         run_parse_seg(job, g_seg_mode == 3 ? 3 : 2);
         return;

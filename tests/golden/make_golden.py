@@ -119,6 +119,16 @@ def main():
         rc, out = R.compress(data, lvl, window_bits=wb, mem_level=ml, strategy=st)
         params.append({"window_bits": wb, "mem_level": ml, "strategy": st, "level": lvl, "rc": rc,
                        "out_len": len(out), "out_sha256": sha(out)})
+    # Z_HUFFMAN_ONLY (2) and Z_RLE (3): their own parse functions, src/deflate.c:2129-2247
+    strategies = []
+    for kind, size, seed in (("text", 30000, 5), ("runs", 70000, 6), ("zero", 66000, 7), ("bitmap", 140000, 8),
+                             ("random", 16384, 9), ("table", 3, 10), ("text", 0, 11)):
+        d2 = corpus.make_buffer(kind, size, seed)
+        for st in (2, 3):
+            for lvl, wb in ((6, 15), (1, 31), (9, -15)):
+                rc, out = R.compress(d2, lvl, window_bits=wb, strategy=st)
+                strategies.append({"kind": kind, "size": size, "seed": seed, "strategy": st, "level": lvl,
+                                   "window_bits": wb, "rc": rc, "out_len": len(out), "out_sha256": sha(out)})
     small = []
     for cap in (0, 1, 2, 100, 12000, 40000):
         rc, out = R.compress(data, 6, dest_cap=cap)
@@ -203,7 +213,7 @@ def main():
         resync.append({"kind": kind, "size": n, "seed": 77, "window_bits": wb, "stream_hex": comp.hex(),
                        "cases": cases})
     json.dump({"deflate": deflate_cases, "streams": streams, "params": params, "small": small,
-               "sections": sections}, open(os.path.join(HERE, "deflate_golden.json"), "w"), indent=0)
+               "sections": sections, "strategies": strategies}, open(os.path.join(HERE, "deflate_golden.json"), "w"), indent=0)
     json.dump({"checksums": sums, "inflate_kat": kats, "corrupt": corrupt, "resync": resync,
                "corrupt_source": {"kind": "text", "size": 20000, "seed": 3, "level": 6}},
               open(os.path.join(HERE, "inflate_golden.json"), "w"), indent=0)

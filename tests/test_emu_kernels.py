@@ -70,8 +70,8 @@ def test_full_pipeline_streams(emu, oracle):
             data = corpus.make_buffer(kind, n, n + 13)
             for level, wrap, wb, strat in ((6, 1, 15, 0), (9, 1, 15, 0), (4, 0, -15, 0), (6, 2, 31, 0),
                                            (6, 1, 15, 4), (6, 1, 15, 1), (1, 1, 15, 0), (2, 2, 31, 0),
-                                           (3, 0, -15, 0)):
-                if n > 40000 and (level, wrap, strat) not in ((6, 1, 0), (1, 1, 0)):
+                                           (3, 0, -15, 0), (6, 1, 15, 2), (6, 2, 31, 3), (1, 1, 15, 3)):
+                if n > 40000 and (level, wrap, strat) not in ((6, 1, 0), (1, 1, 0), (6, 1, 2), (6, 2, 3)):
                     continue
                 rc, got = emu_compress(emu, data, level, wrap, strat)
                 orc, want, _ = oracle.compress(data, level, window_bits=wb, strategy=strat)

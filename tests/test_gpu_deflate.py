@@ -68,7 +68,7 @@ def test_against_oracle_edge_sizes(z, oracle):
 def test_strategies_and_wrappers(z, oracle):
     data = [corpus.make_buffer(k, 50000, 3) for k in ("text", "table", "object", "random")]
     for wb in (15, -15, 31):
-        for strat in (0, 1, 4):
+        for strat in (0, 1, 4, 2, 3):  # default, filtered, fixed, huffman-only, rle
             rc, outs, stats = z.compress_batch(data, level=6, window_bits=wb, strategy=strat)
             assert rc == 0
             for b, o, s in zip(data, outs, stats):
@@ -158,3 +158,16 @@ def test_config3_mix_of_64k_buffers_levels_1_6_9(z, oracle):
         assert outs[:96] == outs[96:192] == outs[-96:]
         rc, back, _, st = z.uncompress_batch(outs[:96], [65536] * 96)
         assert rc == 0 and all(s == 0 for s in st) and back == big[:96]
+
+
+def test_huffman_only_and_rle_golden(z):
+    """Z_HUFFMAN_ONLY / Z_RLE (reference deflate_huff / deflate_rle): outcomes recorded from the
+    reference, including sizes around the 16 383-symbol block cut and the window slide."""
+    for st in (2, 3):
+        for lvl, wb in ((6, 15), (1, 31), (9, -15)):
+            cs = [c for c in G_DEF["strategies"] if (c["strategy"], c["level"], c["window_bits"]) == (st, lvl, wb)]
+            bufs = [corpus.make_buffer(c["kind"], c["size"], c["seed"]) for c in cs]
+            rc, outs, stats = z.compress_batch(bufs, level=lvl, window_bits=wb, strategy=st)
+            assert rc == 0
+            for c, o, s in zip(cs, outs, stats):
+                assert (s, len(o), sha(o)) == (c["rc"], c["out_len"], c["out_sha256"]), c

@@ -38,6 +38,13 @@ def test_deflate_golden_full_streams(oracle):
         assert rc == c["rc"] and out.hex() == c["out_hex"], c
 
 
+def test_deflate_golden_huffman_only_and_rle(oracle):
+    for c in G_DEF["strategies"]:
+        data = corpus.make_buffer(c["kind"], c["size"], c["seed"])
+        rc, out, uns = oracle.compress(data, c["level"], window_bits=c["window_bits"], strategy=c["strategy"])
+        assert not uns and (rc, len(out), sha(out)) == (c["rc"], c["out_len"], c["out_sha256"]), c
+
+
 def test_deflate_golden_params_and_errors(oracle):
     data = corpus.make_buffer("text", 30000, 5)
     for c in G_DEF["params"]:
@@ -168,6 +175,8 @@ def test_oracle_vs_reference_sweep(oracle, reference):
     for n in (0, 5, 300, 5000, 32769, 65275, 65536, 70001, 140000):
         for kind in ("text", "bitmap", "table", "runs", "random"):
             data = corpus.make_buffer(kind, n, n * 7 + 3)
+            for strat in (2, 3):  # Z_HUFFMAN_ONLY, Z_RLE
+                assert reference.compress(data, 6, strategy=strat) == oracle.compress(data, 6, strategy=strat)[:2]
             for level in (1, 3, 4, 6, 9):
                 for wb in (15, -15, 31):
                     if wb != 15 and level != 6:

@@ -58,6 +58,11 @@
 #define SG_EXIT_LAST 3u
 #define SG_EXIT_END 4u
 
+/* the symbol stream of one buffer while it is being assembled */
+typedef struct {
+    uint32_t nsyms, nblocks, blk_sym0, blk_in0, cov;
+} SgOut;
+
 typedef struct {
     uint32_t start_p, start_len, start_at, start_pending;
     uint32_t exit_kind, exit_p, exit_len, exit_at, exit_pending;
@@ -81,8 +86,7 @@ struct SgLds {
     uint32_t chain, chain_ft;     /* where the resolver stands: segment and first valid token */
     uint32_t emu_ascending;       /* test hook of the host emulation: hand segments out bottom-up */
     uint32_t lo, hi, wrap_base;   /* window ring */
-    /* the buffer's symbol stream being assembled */
-    uint32_t nsyms, nblocks, blk_sym0, blk_in0, cov;
+    SgOut out;
     uint32_t cstage[WAVE];
 };
 
@@ -94,17 +98,24 @@ typedef struct {
 
 /* the window base the serial parse has at a loop top at position p: every slide of
  * fill_window (src/deflate.c:1563-1570) whose condition holds at p has happened */
-DEV uint32_t sg_base(uint32_t p, uint32_t n)
+/* `need`: the parser calls fill_window when fewer than `need` bytes of lookahead are left --
+ * MIN_LOOKAHEAD for deflate_slow/_fast (:1898,2002), MAX_MATCH+1 for deflate_rle (:2141),
+ * 1 for deflate_huff (:2218) */
+DEV uint32_t sg_base_at(uint32_t p, uint32_t n, uint32_t need)
 {
     uint32_t base = 0;
     for (;;) {
         uint64_t end = (uint64_t)base + 2ull * ZD_TILE;
         uint32_t data_end = end < n ? (uint32_t)end : n;
-        if ((uint64_t)p + ZD_MIN_LOOKAHEAD > data_end && p - base >= ZD_TILE + ZD_MAX_DIST)
+        if ((uint64_t)p + need > data_end && p - base >= ZD_TILE + ZD_MAX_DIST)
             base += ZD_TILE;
         else
             return base;
     }
+}
+DEV uint32_t sg_base(uint32_t p, uint32_t n)
+{
+    return sg_base_at(p, n, ZD_MIN_LOOKAHEAD);
 }
 
 /* number of segments of the super-step that starts at S0 */
@@ -715,11 +726,11 @@ DEV void sg_phase_parse(const LzJob &job, SgLds *lds, const SgScratch &scr, int 
 
 /* append tokens [from, to) of one wave's round to the buffer's symbol stream,
  * cutting a block whenever it holds ZD_SYM_CAP symbols */
-DEV void sg_append(const LzJob &job, SgLds *lds, const uint32_t *tok, uint32_t from, uint32_t to,
-                   int may_cut)
+DEV void sg_append(const LzJob &job, SgOut *o, const uint32_t *tok, uint32_t from, uint32_t to,
+                   int may_cut, uint32_t cut_delta, uint32_t need)
 {
-    uint32_t nsyms = UNI(lds->nsyms), nblocks = UNI(lds->nblocks);
-    uint32_t blk_sym0 = UNI(lds->blk_sym0), blk_in0 = UNI(lds->blk_in0), cov = UNI(lds->cov);
+    uint32_t nsyms = UNI(o->nsyms), nblocks = UNI(o->nblocks);
+    uint32_t blk_sym0 = UNI(o->blk_sym0), blk_in0 = UNI(o->blk_in0), cov = UNI(o->cov);
     uint32_t i = from;
     while (i < to) {
         /* never let a batch run across a block boundary */
@@ -744,7 +755,8 @@ DEV void sg_append(const LzJob &job, SgLds *lds, const uint32_t *tok, uint32_t f
                 job.syms[nsyms + (uint32_t)LANE] = LV(tk);
         }
         /* start position of the batch's last token: the iteration that emitted it ran
-         * one position later (lazy parse), which is where the block is cut */
+         * cut_delta positions later (1 for the lazy parse, 0 for the greedy ones), which is
+         * where the block is cut */
         const uint32_t last_start = cov + READLANE(tex, cnt - 1);
         nsyms += cnt;
         cov += total;
@@ -757,7 +769,7 @@ DEV void sg_append(const LzJob &job, SgLds *lds, const uint32_t *tok, uint32_t f
                 b->sym_count = ZD_SYM_CAP;
                 b->in_begin = blk_in0;
                 b->in_len = cov - blk_in0;
-                b->stored_ok = blk_in0 >= sg_base(last_start + 1, job.n) ? 1u : 0u;
+                b->stored_ok = blk_in0 >= sg_base_at(last_start + cut_delta, job.n, need) ? 1u : 0u;
                 b->last = 0;
             }
             nblocks++;
@@ -767,11 +779,11 @@ DEV void sg_append(const LzJob &job, SgLds *lds, const uint32_t *tok, uint32_t f
     }
     ON_LANE0
     {
-        lds->nsyms = nsyms;
-        lds->nblocks = nblocks;
-        lds->blk_sym0 = blk_sym0;
-        lds->blk_in0 = blk_in0;
-        lds->cov = cov;
+        o->nsyms = nsyms;
+        o->nblocks = nblocks;
+        o->blk_sym0 = blk_sym0;
+        o->blk_in0 = blk_in0;
+        o->cov = cov;
     }
     WAVE_SYNC();
 }
@@ -787,7 +799,7 @@ DEV void sg_phase_resolve(const LzJob &job, SgLds *lds, const SgScratch &scr, in
     for (;;) {
         const uint32_t kind = UNI(lds->wv[k].exit_kind);
         const uint32_t xp = UNI(lds->wv[k].exit_p);
-        sg_append(job, lds, scr.tok + k * SG_TOKCAP, ft, UNI(lds->wv[k].ntok), 1);
+        sg_append(job, &lds->out, scr.tok + k * SG_TOKCAP, ft, UNI(lds->wv[k].ntok), 1, 1u, ZD_MIN_LOOKAHEAD);
         if (kind == SG_EXIT_SYNCED) {
             const uint32_t t = (xp - S0) / SG_G;
             ft = UNI(scr.sidx[t * SG_TRACE + (xp - S0) % SG_G]);
@@ -827,19 +839,19 @@ DEV void sg_phase_resolve(const LzJob &job, SgLds *lds, const SgScratch &scr, in
             const uint32_t c = UNI(job.in[xp - 1]);
             ON_LANE0 { lds->cstage[0] = c; }
             WAVE_SYNC();
-            sg_append(job, lds, lds->cstage, 0, 1, 0);
+            sg_append(job, &lds->out, lds->cstage, 0, 1, 0, 1u, ZD_MIN_LOOKAHEAD);
         }
         ON_LANE0
         {
-            ZdBlockRec *b = &job.blocks[lds->nblocks];
-            b->sym_begin = lds->blk_sym0;
-            b->sym_count = lds->nsyms - lds->blk_sym0;
-            b->in_begin = lds->blk_in0;
-            b->in_len = job.n - lds->blk_in0;
-            b->stored_ok = lds->blk_in0 >= sg_base(job.n, job.n) ? 1u : 0u;
+            ZdBlockRec *b = &job.blocks[lds->out.nblocks];
+            b->sym_begin = lds->out.blk_sym0;
+            b->sym_count = lds->out.nsyms - lds->out.blk_sym0;
+            b->in_begin = lds->out.blk_in0;
+            b->in_len = job.n - lds->out.blk_in0;
+            b->stored_ok = lds->out.blk_in0 >= sg_base(job.n, job.n) ? 1u : 0u;
             b->last = 1;
-            job.out->nsyms = lds->nsyms;
-            job.out->nblocks = lds->nblocks + 1;
+            job.out->nsyms = lds->out.nsyms;
+            job.out->nblocks = lds->out.nblocks + 1;
             lds->redo = 0;
             lds->finished = 1;
         }
@@ -863,7 +875,7 @@ DEV void sg_init(SgLds *lds, int w)
         lds->chain = lds->chain_ft = 0;
         lds->emu_ascending = 0;
         lds->lo = lds->hi = lds->wrap_base = 0;
-        lds->nsyms = lds->nblocks = lds->blk_sym0 = lds->blk_in0 = lds->cov = 0;
+        lds->out.nsyms = lds->out.nblocks = lds->out.blk_sym0 = lds->out.blk_in0 = lds->out.cov = 0;
         lds->wv[0].start_p = 0;
         lds->wv[0].start_len = 2;
         lds->wv[0].start_at = 0;

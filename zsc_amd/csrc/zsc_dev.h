@@ -25,6 +25,7 @@
 #define ZD_TILE_MASK 32767u
 #define ZD_MAX_DIST 32506u     /* w_size - MIN_LOOKAHEAD, include/zsc/deflate.h:308 */
 #define ZD_MIN_LOOKAHEAD 262u
+#define ZD_MAX_MATCH 258u
 #define ZD_TOO_FAR 4096u
 #define ZD_HASH_BITS 15u       /* mem_level 8, src/deflate.c:347 */
 #define ZD_HASH_MASK 0x7fffu

@@ -26,6 +26,7 @@
 #include "inflate.h"
 #include "lz_parse.h"
 #include "lz_parse_seg.h"
+#include "lz_parse_simple.h"
 #include "zsc_dev.h"
 
 #include "zsc/zsc_conf_private.h"
@@ -222,6 +223,36 @@ __global__ __launch_bounds__(SG_W * 64, 6) void k_parse_seg(const uint8_t *__res
         job.out->nsyms = 0;
         job.out->nblocks = 0xffffffffu; /* reported as Z_STREAM_ERROR by the layout kernel */
     }
+}
+
+/* kernel 2 for Z_HUFFMAN_ONLY and Z_RLE: no chains, no window (lz_parse_simple.h) */
+__global__ __launch_bounds__(64) void k_parse_simple(const uint8_t *__restrict__ in,
+                                                     const ZdBuf *__restrict__ bufs,
+                                                     uint32_t *__restrict__ syms,
+                                                     ZdBlockRec *__restrict__ recs,
+                                                     ZdParseOut *__restrict__ pout, uint32_t nbuf)
+{
+    __shared__ SpLds lds;
+    const uint32_t b = blockIdx.x;
+    if (b >= nbuf)
+        return;
+    const ZdBuf buf = bufs[b];
+    LzJob job;
+    job.in = in + buf.in_off;
+    job.n = buf.in_len;
+    job.sorted = nullptr;
+    job.rank = nullptr;
+    job.hib = nullptr;
+    job.cnt = nullptr;
+    job.syms = syms + buf.sym_off;
+    job.blocks = recs + buf.blk0;
+    job.out = pout + b;
+    job.cfg = ZdLevel();
+    job.strategy = buf.strategy;
+    if (buf.strategy == (uint32_t)Z_HUFFMAN_ONLY)
+        lz_parse_huff(job, &lds);
+    else
+        lz_parse_rle(job, &lds);
 }
 
 /* kernel 2 for levels 1-3 (greedy parse) */
@@ -489,7 +520,8 @@ static bool offloadable(I32 level, I32 window_bits, I32 mem_level, ZlibStrategy 
     if (level == Z_DEFAULT_COMPRESSION)
         level = 6;
     return wb == 15 && mem_level == 8 && level >= 1 && level <= 9 &&
-           (strategy == Z_DEFAULT_STRATEGY || strategy == Z_FILTERED || strategy == Z_FIXED);
+           (strategy == Z_DEFAULT_STRATEGY || strategy == Z_FILTERED || strategy == Z_FIXED ||
+            strategy == Z_HUFFMAN_ONLY || strategy == Z_RLE);
 }
 
 extern "C" ZlibReturn zsc_hip_deflate_plan_layout(U32 count, const U32 *source_lens, I32 level,
@@ -738,15 +770,22 @@ extern "C" ZlibReturn zsc_hip_deflate_plan_run(zsc_hip_deflate_plan *pl, const v
         mark();
         hipLaunchKernelGGL(k_checksum, dim3(sb.count), dim3(64), 0, st, in, bufs, res, sb.count);
         mark();
-        hipLaunchKernelGGL(k_hash_sort, dim3(sb.ntiles), dim3(HS_WAVES * 64), 0, st, in, bufs,
-                           (const uint32_t *)sb.d_tile_owner.p, sorted, tmp_syms, rank, dir,
-                           sb.ntiles);
-        hipLaunchKernelGGL(k_link_prev, dim3(sb.ntiles), dim3(HS_WAVES * 64), 0, st, in, bufs,
-                           (const uint32_t *)sb.d_tile_owner.p, (const uint16_t *)dir,
-                           (const uint16_t *)rank, hib, cnt,
-                           sb.ntiles);
+        /* Z_HUFFMAN_ONLY / Z_RLE look at no earlier data than the previous byte: no chains */
+        const bool simple = pl->strategy == (uint32_t)Z_HUFFMAN_ONLY || pl->strategy == (uint32_t)Z_RLE;
+        if (!simple) {
+            hipLaunchKernelGGL(k_hash_sort, dim3(sb.ntiles), dim3(HS_WAVES * 64), 0, st, in, bufs,
+                               (const uint32_t *)sb.d_tile_owner.p, sorted, tmp_syms, rank, dir,
+                               sb.ntiles);
+            hipLaunchKernelGGL(k_link_prev, dim3(sb.ntiles), dim3(HS_WAVES * 64), 0, st, in, bufs,
+                               (const uint32_t *)sb.d_tile_owner.p, (const uint16_t *)dir,
+                               (const uint16_t *)rank, hib, cnt, sb.ntiles);
+        }
         mark();
-        if (cfg.slow) {
+        if (simple) {
+            hipLaunchKernelGGL(k_parse_simple, dim3(sb.count), dim3(64), 0, st, in, bufs, tmp_syms,
+                               recs, pout, sb.count);
+            mark();
+        } else if (cfg.slow) {
 #define ZSC_LAUNCH_PARSE(LT, FIRST, COUNT)                                                       \
     if ((COUNT) > 0)                                                                             \
     hipLaunchKernelGGL(k_parse<LT>, dim3(COUNT), dim3(64), 0, st, in, bufs,                      \
@@ -772,7 +811,7 @@ extern "C" ZlibReturn zsc_hip_deflate_plan_run(zsc_hip_deflate_plan *pl, const v
                                (const uint32_t *)sb.d_order.p, (const uint32_t *)sorted,
                                (const uint16_t *)rank, (const uint16_t *)hib, tmp_syms, recs,
                                pout, cfg, sb.count);
-        if (!cfg.slow)
+        if (!simple && !cfg.slow)
             mark(); /* levels 1-3: one parse kernel for every length, the short-buffer slot stays empty */
         mark();
         hipLaunchKernelGGL(k_huff_plan, dim3(sb.nslots), dim3(64), 0, st, bufs,
