@@ -138,23 +138,28 @@ class Reference:
         return rc, out.value
 
     def compress(self, data: bytes, level=6, window_bits=15, mem_level=8, strategy=0,
-                 max_block_len=None, dest_cap=None, work_len=COMPRESS_WORK):
+                 max_block_len=None, dest_cap=None, work_len=COMPRESS_WORK, gz_header=None):
+        """gz_header: a ctypes struct laid out like the reference's gz_header (passed by reference)"""
         n = len(data)
         mbl = max(n, 1) if max_block_len is None else max_block_len
         if dest_cap is None:
             rc, dest_cap = self.max_output(n, mbl, level, window_bits, mem_level)
             if rc != 0:
                 dest_cap = n + (n >> 3) + 128
+            if gz_header is not None:
+                dest_cap += 70000 * 3
         dst = C.create_string_buffer(max(dest_cap, 1))
         dl = C.c_uint32(dest_cap)
         rc = self.lib.zsc_compress_gzip2(dst, C.byref(dl), data, n, mbl, self._work, work_len,
-                                         level, window_bits, mem_level, strategy, None)
+                                         level, window_bits, mem_level, strategy,
+                                         None if gz_header is None else C.byref(gz_header))
         return rc, dst.raw[:dl.value]
 
-    def uncompress(self, data: bytes, dest_cap: int, window_bits=15, work_len=UNCOMPRESS_WORK):
+    def uncompress(self, data: bytes, dest_cap: int, window_bits=15, work_len=UNCOMPRESS_WORK, gz_header=None):
         dst = C.create_string_buffer(max(dest_cap, 1))
         dl = C.c_uint32(dest_cap)
         sl = C.c_uint32(len(data))
         rc = self.lib.zsc_uncompress_gzip2(dst, C.byref(dl), data, C.byref(sl), self._work,
-                                           work_len, window_bits, None)
+                                           work_len, window_bits,
+                                           None if gz_header is None else C.byref(gz_header))
         return rc, dst.raw[:dl.value], sl.value

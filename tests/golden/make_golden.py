@@ -129,6 +129,59 @@ def main():
                 rc, out = R.compress(d2, lvl, window_bits=wb, strategy=st)
                 strategies.append({"kind": kind, "size": size, "seed": seed, "strategy": st, "level": lvl,
                                    "window_bits": wb, "rc": rc, "out_len": len(out), "out_sha256": sha(out)})
+    # caller-supplied gzip member headers (write: src/deflate.c:1091-1200, read: src/inflate.c:786-954)
+    from zsc_amd.api import gz_header_for_writing, gz_header_for_reading, gz_header_fields
+    gzh = []
+    d3 = corpus.make_buffer("text", 5000, 21)
+    plain = R.compress(d3, 6, window_bits=31)[1]
+    for k, spec in enumerate((
+            {"text": 1, "time": 0x12345678, "os": 7, "name": "hello.txt", "hcrc": 0},
+            {"text": 0, "time": 1, "os": 255, "comment": "a comment", "hcrc": 1},
+            {"text": 1, "time": 0xffffffff, "os": 3, "extra": "00112233445566", "name": "n", "comment": "", "hcrc": 1},
+            {"text": 0, "time": 0, "os": 0, "extra": "", "hcrc": 0},
+            {"text": 0, "time": 77, "os": 3, "extra": "ab" * 300, "name": "x" * 100, "comment": "y" * 200, "hcrc": 1},
+            {"text": 0, "time": 0, "os": 3, "hcrc": 0})):
+        kw = dict(spec)
+        for f in ("extra",):
+            if f in kw:
+                kw[f] = bytes.fromhex(kw[f])
+        for f in ("name", "comment"):
+            if f in kw:
+                kw[f] = kw[f].encode()
+        for lvl, strat in ((6, 0), (9, 0), (1, 0), (6, 3)):
+            h, keep = gz_header_for_writing(**kw)
+            rc, out = R.compress(d3, lvl, window_bits=31, strategy=strat, gz_header=h)
+            body = R.compress(d3, lvl, window_bits=31, strategy=strat)[1]
+            hlen = len(out) - len(body) + 10
+            assert rc == 0 and out[hlen:] == body[10:]
+            case = {"spec": spec, "level": lvl, "strategy": strat, "rc": rc, "header_hex": out[:hlen].hex(),
+                    "out_len": len(out), "out_sha256": sha(out), "reads": []}
+            if lvl == 6 and strat == 0:
+                for caps in ((0, 0, 0), (4, 5, 3), (1000, 1000, 1000)):
+                    for cut in (None, 3, 11, hlen - 1, hlen + 5):
+                        src = out if cut is None else out[:cut]
+                        hr, bufs = gz_header_for_reading(*caps)
+                        rc2, o2, used = R.uncompress(src, len(d3), 31, gz_header=hr)
+                        case["reads"].append({"caps": caps, "cut": cut, "rc": rc2, "out_len": len(o2),
+                                              "consumed": used, "fields": gz_header_fields(hr, bufs)})
+                # a damaged header crc, a zlib stream read with a gz_header, a small dest
+                bad = bytearray(out)
+                bad[hlen - 1] ^= 0x40
+                hr, bufs = gz_header_for_reading(100, 100, 100)
+                rc2, o2, used = R.uncompress(bytes(bad), len(d3), 31, gz_header=hr)
+                case["bad_last_header_byte"] = {"rc": rc2, "out_len": len(o2), "consumed": used,
+                                                "fields": gz_header_fields(hr, bufs)}
+                for cap in (0, 5, hlen - 1, hlen, hlen + 7):
+                    h, keep = gz_header_for_writing(**kw)
+                    rc3, o3 = R.compress(d3, lvl, window_bits=31, gz_header=h, dest_cap=cap)
+                    case.setdefault("small_dest", []).append({"cap": cap, "rc": rc3, "out_hex": o3.hex()})
+            gzh.append(case)
+    hr, bufs = gz_header_for_reading(10, 10, 10)
+    zl = R.compress(d3, 6, window_bits=15)[1]
+    rc2, o2, used = R.uncompress(zl, len(d3), 47, gz_header=hr)
+    gz_misc = {"zlib_stream_auto_detect": {"rc": rc2, "out_len": len(o2), "fields": gz_header_fields(hr, bufs)},
+               "header_on_zlib_compress": R.compress(d3, 6, window_bits=15, gz_header=gz_header_for_writing()[0])[0],
+               "header_on_zlib_uncompress": R.uncompress(zl, len(d3), 15, gz_header=gz_header_for_reading()[0])[0]}
     small = []
     for cap in (0, 1, 2, 100, 12000, 40000):
         rc, out = R.compress(data, 6, dest_cap=cap)
@@ -213,7 +266,8 @@ def main():
         resync.append({"kind": kind, "size": n, "seed": 77, "window_bits": wb, "stream_hex": comp.hex(),
                        "cases": cases})
     json.dump({"deflate": deflate_cases, "streams": streams, "params": params, "small": small,
-               "sections": sections, "strategies": strategies}, open(os.path.join(HERE, "deflate_golden.json"), "w"), indent=0)
+               "sections": sections, "strategies": strategies,
+               "gz_header": gzh, "gz_header_misc": gz_misc}, open(os.path.join(HERE, "deflate_golden.json"), "w"), indent=0)
     json.dump({"checksums": sums, "inflate_kat": kats, "corrupt": corrupt, "resync": resync,
                "corrupt_source": {"kind": "text", "size": 20000, "seed": 3, "level": 6}},
               open(os.path.join(HERE, "inflate_golden.json"), "w"), indent=0)

@@ -81,3 +81,15 @@ def test_argument_validation_needs_no_gpu():
             assert zsc_amd.compress2(data, level=c["level"], window_bits=c["window_bits"],
                                      mem_level=c["mem_level"], strategy=c["strategy"],
                                      work_len=333600)[0] == c["rc"], c
+
+
+def test_gz_header_argument_errors_need_no_gpu():
+    """a gz_header on a zlib-wrapped call is Z_STREAM_ERROR (deflateSetHeader / inflateGetHeader)"""
+    import zsc_amd
+    data = b"y" * 500
+    m = G_DEF["gz_header_misc"]
+    h, keep = zsc_amd.gz_header_for_writing(name=b"n")
+    assert zsc_amd.compress2(data, window_bits=15, gz_header=h)[0] == m["header_on_zlib_compress"] == -2
+    hr, bufs = zsc_amd.gz_header_for_reading(4, 4, 4)
+    assert zsc_amd.uncompress2(b"\x78\x9c\x03\x00\x00\x00\x00\x01", 10, 15, gz_header=hr)[0] == \
+        m["header_on_zlib_uncompress"] == -2

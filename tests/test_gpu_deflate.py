@@ -171,3 +171,49 @@ def test_huffman_only_and_rle_golden(z):
             assert rc == 0
             for c, o, s in zip(cs, outs, stats):
                 assert (s, len(o), sha(o)) == (c["rc"], c["out_len"], c["out_sha256"]), c
+
+
+def _gz_kw(spec):
+    kw = dict(spec)
+    if "extra" in kw:
+        kw["extra"] = bytes.fromhex(kw["extra"])
+    for f in ("name", "comment"):
+        if f in kw:
+            kw[f] = kw[f].encode()
+    return kw
+
+
+def test_gzip_member_header_fields(z):
+    """zsc_compress_gzip / zsc_uncompress_gzip with a caller's gz_header: the
+    header bytes written, the fields read back (full, truncated, small buffers), header CRC,
+    tiny destinations -- all recorded from the reference."""
+    data = corpus.make_buffer("text", 5000, 21)
+    for c in G_DEF["gz_header"]:
+        h, keep = z.gz_header_for_writing(**_gz_kw(c["spec"]))
+        rc, out = z.compress2(data, level=c["level"], window_bits=31, strategy=c["strategy"], gz_header=h)
+        hl = len(c["header_hex"]) // 2
+        assert (rc, out[:hl].hex(), len(out), sha(out)) == (c["rc"], c["header_hex"], c["out_len"], c["out_sha256"]), c["spec"]
+        for r in c["reads"]:
+            src = out if r["cut"] is None else out[:r["cut"]]
+            hr, bufs = z.gz_header_for_reading(*r["caps"])
+            rc2, o2, used = z.uncompress2(src, len(data), 31, gz_header=hr)
+            assert (rc2, len(o2), used, z.gz_header_fields(hr, bufs)) == \
+                   (r["rc"], r["out_len"], r["consumed"], r["fields"]), (c["spec"], r["caps"], r["cut"])
+        if "bad_last_header_byte" in c:
+            bad = bytearray(out)
+            bad[hl - 1] ^= 0x40
+            hr, bufs = z.gz_header_for_reading(100, 100, 100)
+            rc2, o2, used = z.uncompress2(bytes(bad), len(data), 31, gz_header=hr)
+            b = c["bad_last_header_byte"]
+            assert (rc2, len(o2), used, z.gz_header_fields(hr, bufs)) == (b["rc"], b["out_len"], b["consumed"], b["fields"])
+        for sd in c.get("small_dest", []):
+            h, keep = z.gz_header_for_writing(**_gz_kw(c["spec"]))
+            rc3, o3 = z.compress2(data, level=c["level"], window_bits=31, gz_header=h, dest_len=sd["cap"])
+            assert (rc3, o3.hex()) == (sd["rc"], sd["out_hex"]), (c["spec"], sd["cap"])
+    m = G_DEF["gz_header_misc"]
+    zl = z.compress2(data, level=6)[1]
+    hr, bufs = z.gz_header_for_reading(10, 10, 10)
+    rc2, o2, used = z.uncompress2(zl, len(data), 47, gz_header=hr)
+    assert (rc2, len(o2), z.gz_header_fields(hr, bufs)) == (m["zlib_stream_auto_detect"]["rc"],
+                                                          m["zlib_stream_auto_detect"]["out_len"],
+                                                          m["zlib_stream_auto_detect"]["fields"])

@@ -18,4 +18,5 @@ from .api import (  # noqa: F401
     uncompress_get_min_work_buf_size,
     compress, compress2, compress_gzip, uncompress, uncompress2, uncompress_gzip,
     compress_batch, uncompress_batch, DeflatePlan, InflatePlan,
+    GzHeader, gz_header_for_writing, gz_header_for_reading, gz_header_fields,
 )

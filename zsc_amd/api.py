@@ -124,17 +124,73 @@ def uncompress_get_min_work_buf_size(window_bits: int = DEF_WBITS):
 
 # ---- one-shot calls (reference zsc_pub.h:201-411) ---------------------------------
 
+class GzHeader(C.Structure):
+    """gz_header, reference include/zsc/zlib_types_pub.h:281-296"""
+    _fields_ = [("text", C.c_int32), ("time", C.c_uint32), ("xflags", C.c_int32), ("os", C.c_int32),
+                ("extra", C.c_void_p), ("extra_len", C.c_uint32), ("extra_max", C.c_uint32),
+                ("name", C.c_void_p), ("name_max", C.c_uint32),
+                ("comment", C.c_void_p), ("comm_max", C.c_uint32),
+                ("hcrc", C.c_int32), ("done", C.c_int32)]
+
+
+def gz_header_for_writing(text=0, time=0, os=3, extra: Optional[bytes] = None, name: Optional[bytes] = None,
+                          comment: Optional[bytes] = None, hcrc=0):
+    """A gz_header for zsc_compress_gzip*; returns (struct, buffers to keep alive)."""
+    h = GzHeader()
+    h.text, h.time, h.os, h.hcrc = text, time, os, hcrc
+    keep = []
+    if extra is not None:
+        b = C.create_string_buffer(extra, max(len(extra), 1))
+        keep.append(b)
+        h.extra, h.extra_len = C.addressof(b), len(extra)
+    if name is not None:
+        b = C.create_string_buffer(name + b"\0")
+        keep.append(b)
+        h.name = C.addressof(b)
+    if comment is not None:
+        b = C.create_string_buffer(comment + b"\0")
+        keep.append(b)
+        h.comment = C.addressof(b)
+    return h, keep
+
+
+def gz_header_for_reading(extra_max=0, name_max=0, comm_max=0):
+    """A gz_header for zsc_uncompress_gzip*; returns (struct, (extra, name, comment) buffers)."""
+    h = GzHeader()
+    bufs = []
+    for cap, ptr, mx in ((extra_max, "extra", "extra_max"), (name_max, "name", "name_max"),
+                         (comm_max, "comment", "comm_max")):
+        b = C.create_string_buffer(max(cap, 1)) if cap else None
+        bufs.append(b)
+        if b is not None:
+            setattr(h, ptr, C.addressof(b))
+            setattr(h, mx, cap)
+    return h, tuple(bufs)
+
+
+def gz_header_fields(h: GzHeader, bufs) -> dict:
+    """What a reader finds in the struct afterwards (buffers cut at their capacity)."""
+    extra, name, comment = bufs
+    return {"text": h.text, "time": h.time, "xflags": h.xflags, "os": h.os, "hcrc": h.hcrc, "done": h.done,
+            "extra_len": h.extra_len,
+            "extra": None if not h.extra or extra is None else extra.raw[:min(h.extra_len, h.extra_max)].hex(),
+            "name": None if not h.name or name is None else name.raw.split(b"\0")[0].hex(),
+            "comment": None if not h.comment or comment is None else comment.raw.split(b"\0")[0].hex()}
+
+
 def compress2(source: bytes, max_block_len: Optional[int] = None, level: int = 6,
               window_bits: int = DEF_WBITS, mem_level: int = DEF_MEM_LEVEL,
               strategy: int = Z_DEFAULT_STRATEGY, dest_len: Optional[int] = None,
-              work_len: Optional[int] = None) -> Tuple[int, bytes]:
-    """zsc_compress2 (reference zsc_pub.h:258).  Returns (ZlibReturn, stream bytes)."""
+              work_len: Optional[int] = None, gz_header: Optional[GzHeader] = None) -> Tuple[int, bytes]:
+    """zsc_compress2 / zsc_compress_gzip2 (reference zsc_pub.h:258,290).  Returns (ZlibReturn, stream bytes)."""
     n = len(source)
     mbl = max(n, 1) if max_block_len is None else max_block_len
     if dest_len is None:
         rc, dest_len = compress_get_max_output_size2(n, mbl, level, window_bits, mem_level)
         if rc != Z_OK:
             dest_len = n + (n >> 3) + 128
+        if gz_header is not None:
+            dest_len += 70000 * 3  # extra + name + comment at their largest
     if work_len is None:
         rc, work_len = compress_get_min_work_buf_size(window_bits, mem_level)
         if rc != Z_OK:
@@ -143,7 +199,8 @@ def compress2(source: bytes, max_block_len: Optional[int] = None, level: int = 6
     work = C.create_string_buffer(max(work_len, 1))
     dl = C.c_uint32(dest_len)
     rc = lib.zsc_compress_gzip2(dst, C.byref(dl), source, n, mbl, work, work_len, level,
-                                window_bits, mem_level, strategy, None)
+                                window_bits, mem_level, strategy,
+                                None if gz_header is None else C.byref(gz_header))
     return rc, dst.raw[:dl.value]
 
 
@@ -159,7 +216,7 @@ def compress_gzip(source: bytes, max_block_len: Optional[int] = None, level: int
 
 
 def uncompress2(source: bytes, dest_len: int, window_bits: int = DEF_WBITS,
-                work_len: Optional[int] = None) -> Tuple[int, bytes, int]:
+                work_len: Optional[int] = None, gz_header: Optional[GzHeader] = None) -> Tuple[int, bytes, int]:
     """zsc_uncompress2 (reference zsc_pub.h:385).  Returns (ZlibReturn, bytes, consumed)."""
     if work_len is None:
         rc, work_len = uncompress_get_min_work_buf_size(window_bits)
@@ -169,7 +226,7 @@ def uncompress2(source: bytes, dest_len: int, window_bits: int = DEF_WBITS,
     work = C.create_string_buffer(max(work_len, 1))
     dl, sl = C.c_uint32(dest_len), C.c_uint32(len(source))
     rc = lib.zsc_uncompress_gzip2(dst, C.byref(dl), source, C.byref(sl), work, work_len,
-                                  window_bits, None)
+                                  window_bits, None if gz_header is None else C.byref(gz_header))
     return rc, dst.raw[:dl.value], sl.value
 
 

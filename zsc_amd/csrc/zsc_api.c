@@ -173,6 +173,192 @@ ZlibReturn zsc_uncompress_get_min_work_buf_size(U32 *size_out)
     return zsc_uncompress_get_min_work_buf_size2(DEF_WBITS, size_out);
 }
 
+/* ---- gzip header fields (host side: a few dozen bytes per call) ---------------- */
+
+/* CRC-32 of the gzip member header only (FHCRC); the data CRC is computed on the GPU */
+static U32 hdr_crc32(U32 crc, const U8 *buf, U32 len)
+{
+    crc = ~crc;
+    for (U32 i = 0; i < len; i++) {
+        crc ^= buf[i];
+        for (I32 k = 0; k < 8; k++) {
+            crc = (crc >> 1) ^ (0xEDB88320u & (0u - (crc & 1u)));
+        }
+    }
+    return ~crc;
+}
+
+/* The member header deflate() writes for a caller-supplied gz_header, reference
+ * src/deflate.c:1091-1200.  Writes at most `cap` bytes to `out`, returns the full length. */
+static U32 gz_header_write(const gz_header *h, I32 level, ZlibStrategy strategy, U8 *out, U32 cap)
+{
+    U32 n = 0, crc = 0;
+#define GZ_PUT(byte)                          \
+    do {                                      \
+        const U8 _b = (U8)(byte);             \
+        if (h->hcrc) {                        \
+            crc = hdr_crc32(crc, &_b, 1);     \
+        }                                     \
+        if (n < cap) {                        \
+            out[n] = _b;                      \
+        }                                     \
+        n++;                                  \
+    } while (0)
+    GZ_PUT(31);
+    GZ_PUT(139);
+    GZ_PUT(8);
+    GZ_PUT((h->text ? 1 : 0) + (h->hcrc ? 2 : 0) + (h->extra == Z_NULL ? 0 : 4) +
+           (h->name == Z_NULL ? 0 : 8) + (h->comment == Z_NULL ? 0 : 16));
+    GZ_PUT(h->time & 0xff);
+    GZ_PUT((h->time >> 8) & 0xff);
+    GZ_PUT((h->time >> 16) & 0xff);
+    GZ_PUT((h->time >> 24) & 0xff);
+    GZ_PUT(level == 9 ? 2 : (((I32)strategy >= (I32)Z_HUFFMAN_ONLY || level < 2) ? 4 : 0));
+    GZ_PUT(h->os & 0xff);
+    if (h->extra != Z_NULL) {
+        GZ_PUT(h->extra_len & 0xff);
+        GZ_PUT((h->extra_len >> 8) & 0xff);
+        for (U32 i = 0; i < (h->extra_len & 0xffffu); i++) {
+            GZ_PUT(h->extra[i]);
+        }
+    }
+    if (h->name != Z_NULL) {
+        U32 i = 0;
+        U8 c;
+        do {
+            c = h->name[i++];
+            GZ_PUT(c);
+        } while (c != 0);
+    }
+    if (h->comment != Z_NULL) {
+        U32 i = 0;
+        U8 c;
+        do {
+            c = h->comment[i++];
+            GZ_PUT(c);
+        } while (c != 0);
+    }
+    if (h->hcrc) {
+        const U32 c16 = crc; /* over everything before this field (HCRC_UPDATE, :1062-1068) */
+        if (n < cap) {
+            out[n] = (U8)(c16 & 0xff);
+        }
+        n++;
+        if (n < cap) {
+            out[n] = (U8)((c16 >> 8) & 0xff);
+        }
+        n++;
+    }
+#undef GZ_PUT
+    return n;
+}
+
+/* What inflate() stores through inflateGetHeader while it reads the member header,
+ * reference src/inflate.c:740-954: fields are filled as far as the input reaches; `done`
+ * becomes 1 only after a complete (and, with FHCRC, verified) header, -1 for a zlib stream. */
+static void gz_header_read(gz_header *h, const U8 *src, U32 avail)
+{
+    h->done = 0; /* inflateGetHeader */
+    U32 pos = 0;
+    if (avail < 2) {
+        return;
+    }
+    if (!(src[0] == 31 && src[1] == 139)) {
+        h->done = -1; /* :748-751 */
+        return;
+    }
+    pos = 2;
+    if (avail - pos < 2) {
+        return;
+    }
+    const U32 flags = (U32)src[pos] | ((U32)src[pos + 1] << 8);
+    if ((flags & 0xff) != 8 || (flags & 0xe000)) {
+        return;
+    }
+    h->text = (I32)((flags >> 8) & 1);
+    pos += 2;
+    if (avail - pos < 4) {
+        return;
+    }
+    h->time = (U32)src[pos] | ((U32)src[pos + 1] << 8) | ((U32)src[pos + 2] << 16) |
+              ((U32)src[pos + 3] << 24);
+    pos += 4;
+    if (avail - pos < 2) {
+        return;
+    }
+    h->xflags = (I32)src[pos];
+    h->os = (I32)src[pos + 1];
+    pos += 2;
+    if (flags & 0x0400) {
+        if (avail - pos < 2) {
+            return;
+        }
+        const U32 xlen = (U32)src[pos] | ((U32)src[pos + 1] << 8);
+        h->extra_len = xlen;
+        pos += 2;
+        U32 copy = xlen < avail - pos ? xlen : avail - pos;
+        if (copy != 0 && h->extra != Z_NULL) {
+            const U32 keep = copy > h->extra_max ? h->extra_max : copy;
+            for (U32 i = 0; i < keep; i++) {
+                h->extra[i] = src[pos + i];
+            }
+        }
+        pos += copy;
+        if (copy < xlen) {
+            return;
+        }
+    } else {
+        h->extra = Z_NULL;
+    }
+    if (flags & 0x0800) {
+        if (avail == pos) {
+            return;
+        }
+        U32 stored = 0;
+        U8 c;
+        do {
+            c = src[pos++];
+            if (h->name != Z_NULL && stored < h->name_max) {
+                h->name[stored++] = c;
+            }
+        } while (c != 0 && pos < avail);
+        if (c != 0) {
+            return;
+        }
+    } else {
+        h->name = Z_NULL;
+    }
+    if (flags & 0x1000) {
+        if (avail == pos) {
+            return;
+        }
+        U32 stored = 0;
+        U8 c;
+        do {
+            c = src[pos++];
+            if (h->comment != Z_NULL && stored < h->comm_max) {
+                h->comment[stored++] = c;
+            }
+        } while (c != 0 && pos < avail);
+        if (c != 0) {
+            return;
+        }
+    } else {
+        h->comment = Z_NULL;
+    }
+    if (flags & 0x0200) {
+        if (avail - pos < 2) {
+            return;
+        }
+        const U32 got = (U32)src[pos] | ((U32)src[pos + 1] << 8);
+        if (got != (hdr_crc32(0, src, pos) & 0xffffu)) {
+            return; /* header crc mismatch: the stream is bad, `done` stays 0 */
+        }
+    }
+    h->hcrc = (I32)((flags >> 9) & 1);
+    h->done = 1;
+}
+
 /* ---- compression ------------------------------------------------------------ */
 
 /* reference src/zsc_compress.c:50-160 */
@@ -238,23 +424,36 @@ ZlibReturn zsc_compress_gzip2(U8 *dest, U32 *dest_len, const U8 *source, U32 sou
                  "are not offloaded yet.");
         return Z_STREAM_ERROR;
     }
+    /* A caller-supplied gzip header only changes the member header: the stream is produced
+     * with the plain 10-byte header placed so that it ends where the caller's header ends,
+     * then the caller's header is written over the front (src/deflate.c:1091-1200). */
+    U32 shift = 0;
     if (gz_header != Z_NULL) {
-        ZSC_WARN("In zsc_compress_gzip2(), caller-supplied gzip header fields are not offloaded "
-                 "yet.");
-        return Z_STREAM_ERROR;
+        const U32 hlen = gz_header_write(gz_header, lvl, strategy, dest, 0);
+        if (dest_cap < hlen) {
+            /* not even the header fits: the part that does is delivered, :1085-1090 + wrapper loop */
+            (void)gz_header_write(gz_header, lvl, strategy, dest, dest_cap);
+            *dest_len = dest_cap;
+            ZSC_WARN1("In zsc_compress_gzip2(), deflate ended with error code %d.", Z_BUF_ERROR);
+            return Z_BUF_ERROR;
+        }
+        shift = hlen - 10u;
     }
 
     const U8 *srcs[1] = {source};
-    U8 *dsts[1] = {dest};
+    U8 *dsts[1] = {dest + shift};
     U32 slen[1] = {source_len};
-    U32 dlen[1] = {dest_cap};
+    U32 dlen[1] = {dest_cap - shift};
     I32 stat[1] = {Z_STREAM_ERROR};
     err = zsc_hip_compress_batch(1, srcs, slen, dsts, dlen, stat, level, window_bits, mem_level,
                                  strategy);
     if (err != Z_OK) {
         return err;
     }
-    *dest_len = dlen[0];
+    if (gz_header != Z_NULL) {
+        (void)gz_header_write(gz_header, lvl, strategy, dest, shift + 10u);
+    }
+    *dest_len = dlen[0] + shift;
     if (stat[0] != Z_OK) {
         ZSC_WARN1("In zsc_compress_gzip2(), deflate ended with error code %d.", stat[0]);
         if (dest_cap < bound) {
@@ -322,8 +521,7 @@ ZlibReturn zsc_uncompress_gzip2(U8 *dest, U32 *dest_len, const U8 *source, U32 *
             ZSC_WARN("In zsc_uncompress_gzip2(), could not get header, error -2.");
             return Z_STREAM_ERROR;
         }
-        ZSC_WARN("In zsc_uncompress_gzip2(), returning gzip header fields is not offloaded yet.");
-        return Z_STREAM_ERROR;
+        gz_head->done = 0;
     }
     const U8 *srcs[1] = {source};
     U8 *dsts[1] = {dest};
@@ -336,6 +534,9 @@ ZlibReturn zsc_uncompress_gzip2(U8 *dest, U32 *dest_len, const U8 *source, U32 *
     }
     *dest_len = dlen[0];
     *source_len = slen[0];
+    if (gz_head != Z_NULL) {
+        gz_header_read(gz_head, source, src_avail);
+    }
     if (stat[0] != Z_OK) {
         ZSC_WARN1("In zsc_uncompress_gzip2(), inflate loop failed with error %d.", stat[0]);
     }
