@@ -46,6 +46,22 @@ static const ZdLevel kLevels[10] = {
     {4, 4, 16, 16, 1},     {8, 16, 32, 32, 1},    {8, 16, 128, 128, 1}, {8, 32, 128, 256, 1},
     {32, 128, 258, 1024, 1}, {32, 258, 258, 4096, 1}};
 
+static int g_wbits = 15, g_mem_level = 8; /* emu_set_params: the window_bits / mem_level of the next calls */
+extern "C" void emu_set_params(int wbits, int mem_level)
+{
+    g_wbits = wbits;
+    g_mem_level = mem_level;
+}
+static ZdLevel level_cfg(int level)
+{
+    ZdLevel c = kLevels[level];
+    c.wsize = 1u << g_wbits;
+    c.max_dist = c.wsize - ZD_MIN_LOOKAHEAD;
+    c.sym_cap = (1u << (g_mem_level + 6)) - 1u;
+    c.hbits = (uint32_t)g_mem_level + 7u;
+    return c;
+}
+
 struct EmuChains {
     std::vector<uint8_t> in;
     uint32_t n, ntiles;
@@ -206,7 +222,7 @@ extern "C" int emu_parse(const uint8_t *src, uint32_t n, int level, int strategy
     job.syms = syms;
     job.blocks = blocks;
     job.out = &out;
-    job.cfg = kLevels[level];
+    job.cfg = level_cfg(level);
     job.strategy = (uint32_t)strategy;
     run_parse(job);
     *nsyms = out.nsyms;
@@ -238,7 +254,7 @@ extern "C" int emu_compress(const uint8_t *src, uint32_t n, int level, int wrap,
     EmuChains c;
     build_chains(c, src, n);
     std::vector<uint32_t> syms((size_t)n + 64);
-    uint32_t max_blocks = n / ZD_SYM_CAP + 2;
+    uint32_t max_blocks = n / ((1u << (g_mem_level + 6)) - 1u) + 2;
     std::vector<ZdBlockRec> recs(max_blocks);
     std::vector<ZdBlockPlan> plans(max_blocks);
     ZdParseOut po = {0, 0};
@@ -252,7 +268,7 @@ extern "C" int emu_compress(const uint8_t *src, uint32_t n, int level, int wrap,
     job.syms = syms.data();
     job.blocks = recs.data();
     job.out = &po;
-    job.cfg = kLevels[level];
+    job.cfg = level_cfg(level);
     job.strategy = (uint32_t)strategy;
     run_parse(job);
 
@@ -264,6 +280,7 @@ extern "C" int emu_compress(const uint8_t *src, uint32_t n, int level, int wrap,
     buf.level = (uint32_t)level;
     buf.wrap = (uint32_t)wrap;
     buf.strategy = (uint32_t)strategy;
+    buf.wbits = (uint32_t)g_wbits;
     ZdResult res;
     memset(&res, 0, sizeof res);
     CkLds ck;

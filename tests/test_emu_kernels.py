@@ -142,3 +142,27 @@ def test_inflate_kernel_including_resynchronisation(emu, oracle):
             del comp[rnd.randrange(len(comp)):]
         cap = rnd.choice([n, n + 50, max(1, n // 2)])
         assert emu_uncompress(emu, bytes(comp), cap, wb) == oracle.uncompress(bytes(comp), cap, wb), (i, wb, cap)
+
+
+def test_window_bits_and_mem_level(emu, oracle):
+    """zsc_compress2's window_bits 9..15 and mem_level 1..9: a smaller window
+    moves MAX_DIST and the slide points, mem_level the block cut (lit_bufsize) and -- in one
+    corner -- which candidate at exactly MAX_DIST heads its chain (LZ_HEAD_BLOCKED)."""
+    try:
+        for wb, ml in ((9, 1), (9, 9), (10, 4), (12, 8), (14, 2), (15, 9), (15, 1), (11, 7)):
+            emu.emu_set_params(wb, ml)
+            for n in (0, 3, 513, 763, 5000, 20000, 70000):
+                for kind in ("text", "runs", "table", "bitmap"):
+                    data = corpus.make_buffer(kind, n, n * 3 + wb)
+                    for level, strat in ((6, 0), (1, 0), (9, 0), (6, 3), (6, 2)):
+                        if n > 20000 and level == 9:
+                            continue
+                        for mode in (0, 2) if level >= 4 and strat == 0 else (0,):
+                            emu.emu_set_seg_mode(mode)
+                            rc, got = emu_compress(emu, data, level, 1, strat)
+                            orc, want, _ = oracle.compress(data, level, window_bits=wb, mem_level=ml,
+                                                           strategy=strat, work_len=600000)
+                            assert rc == orc == 0 and got == want, (wb, ml, n, kind, level, strat, mode)
+    finally:
+        emu.emu_set_params(15, 8)
+        emu.emu_set_seg_mode(0)

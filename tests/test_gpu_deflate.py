@@ -217,3 +217,25 @@ def test_gzip_member_header_fields(z):
     assert (rc2, len(o2), z.gz_header_fields(hr, bufs)) == (m["zlib_stream_auto_detect"]["rc"],
                                                           m["zlib_stream_auto_detect"]["out_len"],
                                                           m["zlib_stream_auto_detect"]["fields"])
+
+
+def test_window_bits_and_mem_level(z, oracle):
+    """zsc_compress2 with window_bits 9..15 (and 8 -> 9) and mem_level 1..9: golden parameter
+    cases of the reference, then a sweep against the oracle (pinned on the same parameters)."""
+    data = corpus.make_buffer("text", 30000, 5)
+    for c in G_DEF["params"]:
+        rc, out = z.compress2(data, level=c["level"], window_bits=c["window_bits"], mem_level=c["mem_level"],
+                              strategy=c["strategy"], work_len=333600)  # the work size the golden calls used
+        assert (rc, len(out), sha(out)) == (c["rc"], c["out_len"], c["out_sha256"]), c
+    bufs = [corpus.make_buffer(k, n, n + 3) for k in ("text", "runs", "table", "bitmap", "zero")
+            for n in (0, 600, 5000, 40000, 140000)]
+    for wb, ml in ((9, 1), (9, 9), (10, 4), (12, 8), (14, 2), (15, 9), (15, 1), (-11, 7), (25, 3), (8, 8)):
+        for level, strat in ((6, 0), (1, 0), (9, 0), (6, 3), (6, 2)):
+            rc, outs, stats = z.compress_batch(bufs, level=level, window_bits=wb, mem_level=ml, strategy=strat)
+            assert rc == 0
+            for b, o, s in zip(bufs, outs, stats):
+                orc, want, _ = oracle.compress(b, level, window_bits=wb, mem_level=ml, strategy=strat, work_len=600000)
+                assert s == orc == 0 and o == want, (wb, ml, level, strat, len(b))
+            if wb > 0:
+                rc, back, _, st = z.uncompress_batch(outs, [len(b) for b in bufs], window_bits=wb if wb != 8 else 15)
+                assert rc == 0 and all(x == 0 for x in st) and back == bufs

@@ -336,7 +336,7 @@ DEV void layout_buffer(const ZdBuf *buf, const ZdParseOut *po, const ZdBlockRec 
     }
     if (buf->wrap == 1) {
         /* reference src/deflate.c:1031-1049 */
-        uint32_t h = (8u + (7u << 4)) << 8;
+        uint32_t h = (8u + ((buf->wbits - 8u) << 4)) << 8;
         const uint32_t lvl = buf->level;
         const uint32_t lf = (buf->strategy >= 2 || lvl < 2) ? 0u : lvl < 6 ? 1u : lvl == 6 ? 2u : 3u;
         h |= lf << 6;

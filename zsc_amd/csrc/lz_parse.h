@@ -167,7 +167,7 @@ DEV int lz_put(const LzJob &job, L *lds, LzState &st, uint32_t sym)
     st.nsyms++;
     if (st.nstaged == WAVE)
         lz_flush_stage<L>(job, lds, st);
-    return st.nsyms - st.blk_sym0 == ZD_SYM_CAP;
+    return st.nsyms - st.blk_sym0 == job.cfg.sym_cap;
 }
 
 /* FLUSH_BLOCK_ONLY, reference src/deflate.c:1660-1668 */
@@ -191,9 +191,9 @@ DEV void lz_cut(const LzJob &job, LzState &st, uint32_t upto, uint32_t last)
 /* fill_window's slide decision, reference src/deflate.c:1563-1570,1589 */
 DEV void lz_refill(const LzJob &job, LzState &st, uint32_t p)
 {
-    if (p - st.base >= ZD_TILE + ZD_MAX_DIST)
-        st.base += ZD_TILE;
-    uint64_t end = (uint64_t)st.base + 2ull * ZD_TILE;
+    if (p - st.base >= job.cfg.wsize + job.cfg.max_dist)
+        st.base += job.cfg.wsize;
+    uint64_t end = (uint64_t)st.base + 2ull * job.cfg.wsize;
     st.data_end = end < job.n ? (uint32_t)end : job.n;
 }
 
@@ -260,6 +260,40 @@ DEV void lz_ensure_ranks(const LzJob &job, L *lds, LzState &st, uint32_t p)
         }                                                                                     \
     } while (0)
 
+/* The one place where the reference's hash function shows through.  A candidate at exactly
+ * MAX_DIST is only looked at when it is the HEAD of p's chain (src/deflate.c:2027-2028 tests
+ * the head with <=, the walk :1512 later links with <).  Chains here are those of the 15-bit
+ * hash of mem_level 8; with another mem_level the reference's chains collide differently,
+ * and the candidate is the head only if no position between it and p has p's hash under
+ * THAT function (hash_bits = mem_level + 7, hash_shift = (hash_bits + 2) / 3, :343-350).
+ * Everywhere else collisions cannot matter: a candidate that does not start with p's three
+ * bytes fails the pre-check, and failing is free in zsc.  `MEMB` as in LZ_EVAL_BATCH. */
+#define LZ_HEAD_BLOCKED(Q, P, MEMB, blocked)                                                  \
+    do {                                                                                      \
+        (blocked) = 0;                                                                        \
+        const uint32_t _hs = (job.cfg.hbits + 2u) / 3u, _hm = (1u << job.cfg.hbits) - 1u;     \
+        const uint32_t _wp = UNI(ld_u32(&lds->ring[lz_ridx<L>(st, (P))]));                    \
+        const uint32_t _hp = (((_wp & 0xffu) << (2u * _hs)) ^ (((_wp >> 8) & 0xffu) << _hs) ^ \
+                              ((_wp >> 16) & 0xffu)) & _hm;                                   \
+        for (uint32_t _x0 = (Q) + 1u; _x0 < (P) && !(blocked); _x0 += WAVE) {                 \
+            LANEVAR(int, _same);                                                              \
+            FOR_LANES                                                                         \
+            {                                                                                 \
+                const uint32_t _x = _x0 + (uint32_t)LANE;                                     \
+                int _s = 0;                                                                   \
+                if (_x < (P)) {                                                               \
+                    const uint32_t _w = ld_u32(&lds->ring[lz_ridx<L>(st, _x)]);               \
+                    const uint32_t _h = (((_w & 0xffu) << (2u * _hs)) ^                       \
+                                         (((_w >> 8) & 0xffu) << _hs) ^ ((_w >> 16) & 0xffu)) & _hm; \
+                    _s = _h == _hp && MEMB(_x);                                               \
+                }                                                                             \
+                LV(_same) = _s;                                                               \
+            }                                                                                 \
+            if (BALLOT(_same) != 0)                                                           \
+                (blocked) = 1;                                                                \
+        }                                                                                     \
+    } while (0)
+
 /* search context shared by the batch evaluator */
 typedef struct {
     uint32_t p, h, s01, sb, look, cap, nice;
@@ -295,7 +329,7 @@ typedef struct {
         LANEVAR(int, _reach); /* near enough to be in the window (and so in the LDS ring) */    \
         FOR_LANES                                                                             \
         {                                                                                     \
-            LV(_reach) = LV(_hok) && LV(_q) > st.base && sc.p - LV(_q) <= ZD_MAX_DIST;        \
+            LV(_reach) = LV(_hok) && LV(_q) > st.base && sc.p - LV(_q) <= job.cfg.max_dist;   \
             LV(_inb) = LV(_reach) && MEMB(LV(_q));                                            \
         }                                                                                     \
         const uint64_t _m_reach = BALLOT(_reach);                                             \
@@ -303,7 +337,25 @@ typedef struct {
         const int _head_lane = (!sc.head_seen && _m_in) ? CTZ64(_m_in) : 64;                  \
         FOR_LANES                                                                             \
         {                                                                                     \
-            LV(_alive) = LV(_inb) && (sc.p - LV(_q) < ZD_MAX_DIST || LANE == _head_lane);     \
+            LV(_alive) = LV(_inb) && (sc.p - LV(_q) < job.cfg.max_dist || LANE == _head_lane); \
+        }                                                                                     \
+        if (job.cfg.hbits != 15u) {                                                           \
+            /* another mem_level: the candidate at exactly MAX_DIST lives iff it heads the    \
+             * reference's own chain, wherever it stands in this one */                       \
+            LANEVAR(int, _edge);                                                              \
+            FOR_LANES                                                                         \
+            {                                                                                 \
+                LV(_edge) = LV(_inb) && sc.p - LV(_q) == job.cfg.max_dist;                    \
+            }                                                                                 \
+            if (BALLOT(_edge) != 0) {                                                         \
+                int _blk;                                                                     \
+                LZ_HEAD_BLOCKED(sc.p - job.cfg.max_dist, sc.p, MEMB, _blk);                   \
+                FOR_LANES                                                                     \
+                {                                                                             \
+                    if (LV(_edge))                                                            \
+                        LV(_alive) = !_blk;                                                   \
+                }                                                                             \
+            }                                                                                 \
         }                                                                                     \
         const uint64_t _m_alive = BALLOT(_alive);                                             \
         if (!sc.head_seen) {                                                                  \

@@ -101,21 +101,21 @@ typedef struct {
 /* `need`: the parser calls fill_window when fewer than `need` bytes of lookahead are left --
  * MIN_LOOKAHEAD for deflate_slow/_fast (:1898,2002), MAX_MATCH+1 for deflate_rle (:2141),
  * 1 for deflate_huff (:2218) */
-DEV uint32_t sg_base_at(uint32_t p, uint32_t n, uint32_t need)
+DEV uint32_t sg_base_at(const ZdLevel &cfg, uint32_t p, uint32_t n, uint32_t need)
 {
     uint32_t base = 0;
     for (;;) {
-        uint64_t end = (uint64_t)base + 2ull * ZD_TILE;
+        uint64_t end = (uint64_t)base + 2ull * cfg.wsize;
         uint32_t data_end = end < n ? (uint32_t)end : n;
-        if ((uint64_t)p + need > data_end && p - base >= ZD_TILE + ZD_MAX_DIST)
-            base += ZD_TILE;
+        if ((uint64_t)p + need > data_end && p - base >= cfg.wsize + cfg.max_dist)
+            base += cfg.wsize;
         else
             return base;
     }
 }
-DEV uint32_t sg_base(uint32_t p, uint32_t n)
+DEV uint32_t sg_base(const ZdLevel &cfg, uint32_t p, uint32_t n)
 {
-    return sg_base_at(p, n, ZD_MIN_LOOKAHEAD);
+    return sg_base_at(cfg, p, n, ZD_MIN_LOOKAHEAD);
 }
 
 /* number of segments of the super-step that starts at S0 */
@@ -247,6 +247,28 @@ DEV void sg_phase_begin(const LzJob &job, SgLds *lds, int w)
             LV(_alive) = _v == 0 || (_v < total && q > floor_pos); /* :1519 */                \
             LV(_dead) = _v != 0 && _v < total && q <= floor_pos;                              \
         }                                                                                     \
+        if (job.cfg.hbits != 15u) {                                                           \
+            /* with another mem_level the candidate at exactly MAX_DIST can be the head of the \
+             * reference's chain without being the first one here (LZ_HEAD_BLOCKED) */        \
+            LANEVAR(int, _edge);                                                              \
+            FOR_LANES                                                                         \
+            {                                                                                 \
+                LV(_edge) = LV(_dead) && LV(_q) > st.base && p - LV(_q) == job.cfg.max_dist;  \
+            }                                                                                 \
+            if (BALLOT(_edge) != 0) {                                                         \
+                int _blk;                                                                     \
+                LZ_HEAD_BLOCKED(p - job.cfg.max_dist, p, LZ_MEMB_ALL, _blk);                  \
+                if (!_blk) {                                                                  \
+                    FOR_LANES                                                                 \
+                    {                                                                         \
+                        if (LV(_edge)) {                                                      \
+                            LV(_alive) = 1;                                                   \
+                            LV(_dead) = 0;                                                    \
+                        }                                                                     \
+                    }                                                                         \
+                }                                                                             \
+            }                                                                                 \
+        }                                                                                     \
         const uint64_t _m_dead = BALLOT(_dead);                                               \
         SG_COUNT(0, 1);                                                                       \
         FOR_LANES                                                                             \
@@ -335,7 +357,13 @@ DEV void sg_phase_begin(const LzJob &job, SgLds *lds, int w)
 #define SG_SWEEP(Q0)                                                                          \
     do {                                                                                      \
         uint32_t _qn = (Q0);                    /* newest position not looked at yet */      \
-        const uint32_t _qlo = floor_pos + 1u;   /* oldest live position (:1519) */            \
+        uint32_t _qlo = floor_pos + 1u;         /* oldest live position (:1519) */            \
+        if (job.cfg.hbits != 15u && floor_pos > st.base && p - floor_pos == job.cfg.max_dist) { \
+            int _blk; /* the position at exactly MAX_DIST counts if it heads the reference's chain */ \
+            LZ_HEAD_BLOCKED(floor_pos, p, LZ_MEMB_ALL, _blk);                                 \
+            if (!_blk)                                                                        \
+                _qlo = floor_pos;                                                             \
+        }                                                                                     \
         while (!fin && _qn >= _qlo) {                                                         \
             const uint32_t _off = best - 1u;                                                  \
             const uint32_t _rtop = _qn + _off, _rlo = _qlo + _off;                            \
@@ -431,9 +459,9 @@ DEV void sg_parse_segment(const LzJob &job, SgLds *lds, const SgScratch &scr, ui
     const uint32_t a_s = S0 + s * SG_G;
     const uint32_t e_s = a_s + SG_G < E ? a_s + SG_G : E;
 
-    st.base = sg_base(p, job.n);
+    st.base = sg_base(job.cfg, p, job.n);
     {
-        uint64_t end = (uint64_t)st.base + 2ull * ZD_TILE;
+        uint64_t end = (uint64_t)st.base + 2ull * job.cfg.wsize;
         st.data_end = end < job.n ? (uint32_t)end : job.n;
     }
     uint32_t *tok = scr.tok + s * SG_TOKCAP;
@@ -539,7 +567,7 @@ DEV void sg_parse_segment(const LzJob &job, SgLds *lds, const SgScratch &scr, ui
                 const int32_t hiA = (int32_t)(rh & 0xffffu) - 1, hiB = (int32_t)(rh >> 16);
                 const uint32_t tileA = p & ~ZD_TILE_MASK;
                 const uint32_t *runA = job.sorted + (uint64_t)(p >> 15) * ZD_TILE;
-                const uint32_t floor_pos = p - st.base > ZD_MAX_DIST ? p - ZD_MAX_DIST : st.base;
+                const uint32_t floor_pos = p - st.base > job.cfg.max_dist ? p - job.cfg.max_dist : st.base;
                 const uint32_t cap = look < 258u ? look : 258u;
                 const uint32_t nice = job.cfg.nice < look ? job.cfg.nice : look;
                 uint32_t best = prev_len, where = cur_at, sb = 0;
@@ -560,7 +588,13 @@ DEV void sg_parse_segment(const LzJob &job, SgLds *lds, const SgScratch &scr, ui
                 /* the chain head may lie at exactly MAX_DIST (:2032), later links may not */
                 const uint32_t ent0 = READLANE(e0, 0);
                 const uint32_t q0 = tileA + (ent0 & ZD_TILE_MASK) - (nA ? 0u : ZD_TILE);
-                if (!(q0 > st.base && p - q0 <= ZD_MAX_DIST)) {
+                int head_ok = q0 > st.base && p - q0 <= job.cfg.max_dist;
+                if (head_ok && p - q0 == job.cfg.max_dist && job.cfg.hbits != 15u) {
+                    int blocked;
+                    LZ_HEAD_BLOCKED(q0, p, LZ_MEMB_ALL, blocked);
+                    head_ok = !blocked;
+                }
+                if (!head_ok) {
                     fin = 2; /* no chain head in the window: longest_match is not called */
                 } else {
                     head_seen = 1;
@@ -725,7 +759,7 @@ DEV void sg_phase_parse(const LzJob &job, SgLds *lds, const SgScratch &scr, int 
 }
 
 /* append tokens [from, to) of one wave's round to the buffer's symbol stream,
- * cutting a block whenever it holds ZD_SYM_CAP symbols */
+ * cutting a block whenever it holds lit_bufsize-1 symbols */
 DEV void sg_append(const LzJob &job, SgOut *o, const uint32_t *tok, uint32_t from, uint32_t to,
                    int may_cut, uint32_t cut_delta, uint32_t need)
 {
@@ -734,7 +768,7 @@ DEV void sg_append(const LzJob &job, SgOut *o, const uint32_t *tok, uint32_t fro
     uint32_t i = from;
     while (i < to) {
         /* never let a batch run across a block boundary */
-        uint32_t room = may_cut ? ZD_SYM_CAP - (nsyms - blk_sym0) : WAVE;
+        uint32_t room = may_cut ? job.cfg.sym_cap - (nsyms - blk_sym0) : WAVE;
         uint32_t cnt = to - i < WAVE ? to - i : WAVE;
         if (cnt > room)
             cnt = room;
@@ -761,15 +795,15 @@ DEV void sg_append(const LzJob &job, SgOut *o, const uint32_t *tok, uint32_t fro
         nsyms += cnt;
         cov += total;
         i += cnt;
-        if (may_cut && nsyms - blk_sym0 == ZD_SYM_CAP) {
+        if (may_cut && nsyms - blk_sym0 == job.cfg.sym_cap) {
             ON_LANE0
             {
                 ZdBlockRec *b = &job.blocks[nblocks];
                 b->sym_begin = blk_sym0;
-                b->sym_count = ZD_SYM_CAP;
+                b->sym_count = job.cfg.sym_cap;
                 b->in_begin = blk_in0;
                 b->in_len = cov - blk_in0;
-                b->stored_ok = blk_in0 >= sg_base_at(last_start + cut_delta, job.n, need) ? 1u : 0u;
+                b->stored_ok = blk_in0 >= sg_base_at(job.cfg, last_start + cut_delta, job.n, need) ? 1u : 0u;
                 b->last = 0;
             }
             nblocks++;
@@ -848,7 +882,7 @@ DEV void sg_phase_resolve(const LzJob &job, SgLds *lds, const SgScratch &scr, in
             b->sym_count = lds->out.nsyms - lds->out.blk_sym0;
             b->in_begin = lds->out.blk_in0;
             b->in_len = job.n - lds->out.blk_in0;
-            b->stored_ok = lds->out.blk_in0 >= sg_base(job.n, job.n) ? 1u : 0u;
+            b->stored_ok = lds->out.blk_in0 >= sg_base(job.cfg, job.n, job.n) ? 1u : 0u;
             b->last = 1;
             job.out->nsyms = lds->out.nsyms;
             job.out->nblocks = lds->out.nblocks + 1;

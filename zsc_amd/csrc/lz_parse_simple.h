@@ -46,7 +46,7 @@ DEV void sp_finish(const LzJob &job, SpLds *lds, uint32_t need)
         b->sym_count = lds->out.nsyms - lds->out.blk_sym0;
         b->in_begin = lds->out.blk_in0;
         b->in_len = job.n - lds->out.blk_in0;
-        b->stored_ok = lds->out.blk_in0 >= sg_base_at(job.n, job.n, need) ? 1u : 0u;
+        b->stored_ok = lds->out.blk_in0 >= sg_base_at(job.cfg, job.n, job.n, need) ? 1u : 0u;
         b->last = 1;
         job.out->nsyms = lds->out.nsyms;
         job.out->nblocks = lds->out.nblocks + 1;

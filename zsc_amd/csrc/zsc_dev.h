@@ -43,6 +43,12 @@
 typedef struct {
     uint16_t good, lazy, nice, chain;
     uint32_t slow; /* 1: lazy parse (levels 4-9), 0: greedy (1-3) */
+    /* from window_bits / mem_level (reference src/deflate.c:343-362): */
+    uint32_t wsize;    /* 1 << window_bits: the window slides by this much */
+    uint32_t max_dist; /* wsize - MIN_LOOKAHEAD */
+    uint32_t sym_cap;  /* lit_bufsize - 1 = (1 << (mem_level + 6)) - 1 symbols per block */
+    uint32_t hbits;    /* hash_bits = mem_level + 7; the chains are built on the 15-bit hash of
+                          mem_level 8, which only matters in one corner (lz_head_blocked) */
 } ZdLevel;
 
 /* one buffer of a batch */
@@ -59,8 +65,8 @@ typedef struct {
     uint32_t max_blocks;
     uint32_t level;     /* 1..9 */
     uint32_t wrap;      /* 0 raw, 1 zlib, 2 gzip */
-    uint32_t strategy;  /* 0 default, 1 filtered, 4 fixed */
-    uint32_t pad;
+    uint32_t strategy;  /* 0 default, 1 filtered, 2 huffman only, 3 rle, 4 fixed */
+    uint32_t wbits;     /* 9..15, for the zlib header */
 } ZdBuf;
 
 /* what the parser reports per buffer */

@@ -153,6 +153,7 @@ __global__ __launch_bounds__(64) void k_parse(const uint8_t *__restrict__ in,
 
 /* kernel 2 for long buffers at levels 4-9: SG_W wavefronts share one window and parse
  * SG_W segments of the same buffer at once (lz_parse_seg.h) */
+template <bool GENERIC> /* false: window_bits 15 / mem_level 8, their constants folded in */
 __global__ __launch_bounds__(SG_W * 64, 6) void k_parse_seg(const uint8_t *__restrict__ in,
                                                          const ZdBuf *__restrict__ bufs,
                                                          const uint32_t *__restrict__ order,
@@ -184,6 +185,12 @@ __global__ __launch_bounds__(SG_W * 64, 6) void k_parse_seg(const uint8_t *__res
     job.blocks = recs + buf.blk0;
     job.out = pout + b;
     job.cfg = cfg;
+    if (!GENERIC) {
+        job.cfg.wsize = ZD_TILE;
+        job.cfg.max_dist = ZD_MAX_DIST;
+        job.cfg.sym_cap = ZD_SYM_CAP;
+        job.cfg.hbits = 15u;
+    }
     job.strategy = buf.strategy;
     SgScratch scr;
     scr.tok = seg_tok + (uint64_t)blockIdx.x * (SG_NS * SG_TOKCAP);
@@ -230,7 +237,8 @@ __global__ __launch_bounds__(64) void k_parse_simple(const uint8_t *__restrict__
                                                      const ZdBuf *__restrict__ bufs,
                                                      uint32_t *__restrict__ syms,
                                                      ZdBlockRec *__restrict__ recs,
-                                                     ZdParseOut *__restrict__ pout, uint32_t nbuf)
+                                                     ZdParseOut *__restrict__ pout,
+                                                     const ZdLevel cfg, uint32_t nbuf)
 {
     __shared__ SpLds lds;
     const uint32_t b = blockIdx.x;
@@ -247,7 +255,7 @@ __global__ __launch_bounds__(64) void k_parse_simple(const uint8_t *__restrict__
     job.syms = syms + buf.sym_off;
     job.blocks = recs + buf.blk0;
     job.out = pout + b;
-    job.cfg = ZdLevel();
+    job.cfg = cfg;
     job.strategy = buf.strategy;
     if (buf.strategy == (uint32_t)Z_HUFFMAN_ONLY)
         lz_parse_huff(job, &lds);
@@ -472,7 +480,7 @@ struct SubBatch {
 
 struct zsc_hip_deflate_plan {
     uint32_t count = 0;
-    int level = 6, wrap = 1;
+    int level = 6, wrap = 1, wbits = 15, mem_level = 8;
     uint32_t strategy = 0;
     std::vector<ZdBuf> bufs; /* in_off / out_off are absolute in the caller's buffers */
     std::vector<SubBatch> subs;
@@ -506,7 +514,8 @@ extern "C" const char *zsc_hip_device_info(void)
 /* reference deflateBoundNoStream + zsc_compress_get_max_output_size2; defined in zsc_api.c */
 extern "C" ZlibReturn zsc_compress_get_max_output_size2(U32, U32, I32, I32, I32, U32 *);
 
-static bool offloadable(I32 level, I32 window_bits, I32 mem_level, ZlibStrategy strategy, int *wrap)
+static bool offloadable(I32 level, I32 window_bits, I32 mem_level, ZlibStrategy strategy, int *wrap,
+                        int *wbits)
 {
     int wb = window_bits;
     *wrap = 1;
@@ -517,9 +526,12 @@ static bool offloadable(I32 level, I32 window_bits, I32 mem_level, ZlibStrategy 
         *wrap = 2;
         wb -= 16;
     }
+    if (wb == 8 && *wrap == 1)
+        wb = 9; /* reference src/deflate.c:329-331 */
+    *wbits = wb;
     if (level == Z_DEFAULT_COMPRESSION)
         level = 6;
-    return wb == 15 && mem_level == 8 && level >= 1 && level <= 9 &&
+    return wb >= 9 && wb <= 15 && mem_level >= 1 && mem_level <= 9 && level >= 1 && level <= 9 &&
            (strategy == Z_DEFAULT_STRATEGY || strategy == Z_FILTERED || strategy == Z_FIXED ||
             strategy == Z_HUFFMAN_ONLY || strategy == Z_RLE);
 }
@@ -566,8 +578,8 @@ extern "C" ZlibReturn zsc_hip_deflate_plan_create(zsc_hip_deflate_plan **plan_ou
     *plan_out = nullptr;
     if (zsc_hip_init(-1) != Z_OK)
         return Z_STREAM_ERROR;
-    int wrap = 1;
-    if (!offloadable(level, window_bits, mem_level, strategy, &wrap)) {
+    int wrap = 1, wbits = 15;
+    if (!offloadable(level, window_bits, mem_level, strategy, &wrap, &wbits)) {
         ZSC_WARN4("zsc_hip: level %d / window_bits %d / mem_level %d / strategy %d is not "
                   "offloaded to the GPU yet (DESIGN.md, out of scope).",
                   level, window_bits, mem_level, (int)strategy);
@@ -579,6 +591,8 @@ extern "C" ZlibReturn zsc_hip_deflate_plan_create(zsc_hip_deflate_plan **plan_ou
     pl->count = count;
     pl->level = level;
     pl->wrap = wrap;
+    pl->wbits = wbits;
+    pl->mem_level = mem_level;
     pl->strategy = (uint32_t)strategy;
     pl->bufs.resize(count);
 
@@ -610,13 +624,14 @@ extern "C" ZlibReturn zsc_hip_deflate_plan_create(zsc_hip_deflate_plan **plan_ou
             b.out_cap = out_caps[i];
             b.ntiles = n == 0 ? 1u : (n + ZD_TILE - 1) / ZD_TILE;
             b.tile0 = sb.ntiles;
-            b.max_blocks = n / ZD_SYM_CAP + 2;
+            b.max_blocks = n / ((1u << (mem_level + 6)) - 1u) + 2;
             b.blk0 = sb.nslots;
             b.sym_off = sb.nsym_slots;
             b.rank_off = sb.nsym_slots; /* one u16 per (padded) input position */
             b.level = (uint32_t)level;
             b.wrap = (uint32_t)wrap;
             b.strategy = (uint32_t)strategy;
+            b.wbits = (uint32_t)wbits;
             sb.ntiles += b.ntiles;
             sb.nslots += b.max_blocks;
             sb.nsym_slots += ((uint64_t)n + 64u) & ~63ull;
@@ -738,7 +753,11 @@ extern "C" ZlibReturn zsc_hip_deflate_plan_run(zsc_hip_deflate_plan *pl, const v
     pl->last_stream = st;
     const uint8_t *in = (const uint8_t *)d_input;
     uint8_t *out = (uint8_t *)d_output;
-    const ZdLevel cfg = kLevels[pl->level];
+    ZdLevel cfg = kLevels[pl->level];
+    cfg.wsize = 1u << pl->wbits;                 /* reference src/deflate.c:343-346 */
+    cfg.max_dist = cfg.wsize - ZD_MIN_LOOKAHEAD; /* MAX_DIST, include/zsc/deflate.h:304 */
+    cfg.sym_cap = (1u << (pl->mem_level + 6)) - 1u; /* lit_bufsize - 1, :362 + deflate.h:338-354 */
+    cfg.hbits = (uint32_t)pl->mem_level + 7u;
 
     const size_t nev = pl->events_used + pl->subs.size() * ZSC_HIP_NKERNELS;
     if (pl->profile) {
@@ -783,7 +802,7 @@ extern "C" ZlibReturn zsc_hip_deflate_plan_run(zsc_hip_deflate_plan *pl, const v
         mark();
         if (simple) {
             hipLaunchKernelGGL(k_parse_simple, dim3(sb.count), dim3(64), 0, st, in, bufs, tmp_syms,
-                               recs, pout, sb.count);
+                               recs, pout, cfg, sb.count);
             mark();
         } else if (cfg.slow) {
 #define ZSC_LAUNCH_PARSE(LT, FIRST, COUNT)                                                       \
@@ -792,14 +811,15 @@ extern "C" ZlibReturn zsc_hip_deflate_plan_run(zsc_hip_deflate_plan *pl, const v
                        (const uint32_t *)sb.d_order.p, (const uint32_t *)sorted,                 \
                        (const uint16_t *)rank, (const uint16_t *)hib, tmp_syms, recs, pout, cfg, \
                        (uint32_t)(FIRST), (uint32_t)(COUNT))
-            if (pl->use_seg && sb.c36 > 0)
-                hipLaunchKernelGGL(k_parse_seg, dim3(sb.c36), dim3(SG_W * 64), 0, st, in, bufs,
+            if (pl->use_seg && sb.c36 > 0) {
+                auto kern = (pl->wbits == 15 && pl->mem_level == 8) ? k_parse_seg<false> : k_parse_seg<true>;
+                hipLaunchKernelGGL(kern, dim3(sb.c36), dim3(SG_W * 64), 0, st, in, bufs,
                                    (const uint32_t *)sb.d_order.p, (const uint32_t *)sorted,
                                    (const uint16_t *)rank, (const uint16_t *)hib,
                                    (const uint32_t *)cnt, tmp_syms, recs,
                                    pout, (uint32_t *)pl->d_seg_tok.p, (uint16_t *)pl->d_seg_sidx.p,
                                    cfg, 0u, sb.c36);
-            else
+            } else
                 ZSC_LAUNCH_PARSE(LzLds, 0, sb.c36);
             mark();
             ZSC_LAUNCH_PARSE(LzLds16k, sb.c36, sb.c16 - sb.c36);
