@@ -202,7 +202,15 @@ typedef struct {
     zo_block *blocks;
     uint32_t nblocks;
     uint32_t block_begin_sym, block_begin_in;
+    /* where the parse stands (the parse functions can be left at an event and re-entered) */
+    uint32_t p;            /* strstart */
+    uint32_t cur_len, cur_at; /* match_length, match_start */
+    int have_pending;      /* match_available */
+    uint32_t glen, gat;    /* deflate_fast's match_length / match_start */
+    uint32_t insert;       /* strings at the end of the data seen so far that could not be indexed yet */
 } zo_parser;
+
+enum { ZO_EV_BLOCK = 1, ZO_EV_END = 2 }; /* a block was cut / the data seen so far is used up */
 
 /* UPDATE_HASH applied to three consecutive bytes, src/deflate.c:174-175,1593-1596 */
 static inline uint32_t zo_hash3(const zo_parser *z, uint32_t p)
@@ -233,6 +241,18 @@ static void zo_refill(zo_parser *z, uint32_t p)
         z->base += z->wsize;
     uint64_t end = (uint64_t)z->base + 2u * (uint64_t)z->wsize;
     z->data_end = end < z->n ? (uint32_t)end : z->n;
+    /* :1591-1612: strings that ended the previous call's input without three bytes to hash */
+    uint32_t look = z->data_end - p;
+    if (z->insert && look + z->insert >= 3) {
+        uint32_t str = p - z->insert;
+        while (z->insert) {
+            (void)zo_insert(z, str);
+            str++;
+            z->insert--;
+            if (look + z->insert < 3)
+                break;
+        }
+    }
 }
 
 /* longest_match, src/deflate.c:1400-1518.  `cur` is the chain head (already
@@ -323,33 +343,32 @@ static inline int zo_put_match(zo_parser *z, uint32_t dist, uint32_t len)
     return z->nsyms - z->block_begin_sym == z->sym_cap;
 }
 
-/* deflate_slow, src/deflate.c:1989-2122 (levels 4-9), flush == Z_FINISH */
-static void zo_parse_lazy(zo_parser *z)
+/* deflate_slow, src/deflate.c:1989-2122 (levels 4-9): runs until a block is cut or the data
+ * seen so far (z->n) is used up */
+static int zo_run_lazy(zo_parser *z)
 {
-    uint32_t p = 0, cur_len = 2, cur_at = 0;
-    int have_pending = 0; /* match_available */
-
     for (;;) {
+        uint32_t p = z->p;
         uint32_t look = z->data_end - p;
         if (look < ZO_MIN_LOOKAHEAD) {
             zo_refill(z, p);
             look = z->data_end - p;
             if (look == 0)
-                break;
+                return ZO_EV_END;
         }
         uint32_t head = 0; /* absolute 0 is never > base, i.e. NIL */
         if (look >= 3)
             head = zo_insert(z, p);
 
-        uint32_t prev_len = cur_len, prev_at = cur_at;
-        cur_len = 2;
+        uint32_t prev_len = z->cur_len, prev_at = z->cur_at;
+        z->cur_len = 2;
         if (head > z->base && prev_len < z->cfg.lazy && p - head <= z->max_dist) {
-            cur_len = zo_longest(z, p, head, prev_len, &cur_at);
+            z->cur_len = zo_longest(z, p, head, prev_len, &z->cur_at);
             /* :2038-2047 */
-            if (cur_len <= 5 && (z->strategy == 1 || (cur_len == 3 && p - cur_at > ZO_TOO_FAR)))
-                cur_len = 2;
+            if (z->cur_len <= 5 && (z->strategy == 1 || (z->cur_len == 3 && p - z->cur_at > ZO_TOO_FAR)))
+                z->cur_len = 2;
         }
-        if (prev_len >= 3 && cur_len <= prev_len) {
+        if (prev_len >= 3 && z->cur_len <= prev_len) {
             /* the match found one byte back wins (:2052-2082) */
             uint32_t last_insert = p + look - 3;
             int full = zo_put_match(z, p - 1 - prev_at, prev_len);
@@ -358,48 +377,51 @@ static void zo_parse_lazy(zo_parser *z)
                 if (p <= last_insert)
                     (void)zo_insert(z, p);
             }
-            have_pending = 0;
-            cur_len = 2;
+            z->have_pending = 0;
+            z->cur_len = 2;
             p++;
-            if (full)
+            z->p = p;
+            if (full) {
                 zo_cut_block(z, p, 0);
-        } else if (have_pending) {
+                return ZO_EV_BLOCK;
+            }
+        } else if (z->have_pending) {
             /* :2084-2097: previous byte goes out as a literal */
-            if (zo_put_literal(z, z->in[p - 1]))
-                zo_cut_block(z, p, 0);
-            p++;
+            int full = zo_put_literal(z, z->in[p - 1]);
+            z->p = p + 1;
+            if (full) {
+                zo_cut_block(z, p, 0); /* FLUSH_BLOCK_ONLY comes before strstart++ (:2091-2095) */
+                return ZO_EV_BLOCK;
+            }
         } else {
-            have_pending = 1;
-            p++;
+            z->have_pending = 1;
+            z->p = p + 1;
         }
     }
-    if (have_pending)
-        (void)zo_put_literal(z, z->in[p - 1]); /* :2109-2112 */
-    zo_cut_block(z, p, 1);                     /* :2114-2117 */
 }
 
-/* deflate_fast, src/deflate.c:1886-1982 (levels 1-3), flush == Z_FINISH */
-static void zo_parse_greedy(zo_parser *z)
+/* deflate_fast, src/deflate.c:1886-1982 (levels 1-3) */
+static int zo_run_greedy(zo_parser *z)
 {
-    uint32_t p = 0, len = 0, at = 0;
-
     for (;;) {
+        uint32_t p = z->p;
         uint32_t look = z->data_end - p;
         if (look < ZO_MIN_LOOKAHEAD) {
             zo_refill(z, p);
             look = z->data_end - p;
             if (look == 0)
-                break;
+                return ZO_EV_END;
         }
         uint32_t head = 0;
         if (look >= 3)
             head = zo_insert(z, p);
         if (head > z->base && p - head <= z->max_dist)
-            len = zo_longest(z, p, head, 2, &at); /* prev_length stays MIN_MATCH-1 */
+            z->glen = zo_longest(z, p, head, 2, &z->gat); /* prev_length stays MIN_MATCH-1 */
 
         int full;
+        uint32_t len = z->glen;
         if (len >= 3) {
-            full = zo_put_match(z, p - at, len);
+            full = zo_put_match(z, p - z->gat, len);
             look -= len;
             if (len <= z->cfg.lazy /* max_insert_length */ && look >= 3) {
                 /* :1940-1950: short match, index every covered position */
@@ -408,31 +430,34 @@ static void zo_parse_greedy(zo_parser *z)
                     (void)zo_insert(z, p);
                 }
                 p++;
+                z->glen = 0;
             } else {
                 p += len; /* :1951-1962: long match, skip without indexing */
-                len = 0;
+                z->glen = 0;
             }
         } else {
             full = zo_put_literal(z, z->in[p]);
             p++;
         }
-        if (full)
+        z->p = p;
+        if (full) {
             zo_cut_block(z, p, 0);
+            return ZO_EV_BLOCK;
+        }
     }
-    zo_cut_block(z, p, 1);
 }
 
 /* deflate_rle, src/deflate.c:2129-2204 (Z_RLE): only runs -- matches at distance 1 */
-static void zo_parse_rle(zo_parser *z)
+static int zo_run_rle(zo_parser *z)
 {
-    uint32_t p = 0;
     for (;;) {
+        uint32_t p = z->p;
         uint32_t look = z->data_end - p;
         if (look <= 258) { /* :2141 */
             zo_refill(z, p);
             look = z->data_end - p;
             if (look == 0)
-                break;
+                return ZO_EV_END;
         }
         uint32_t len = 0;
         if (look >= 3 && p > 0) { /* strstart > 0: only the very first byte has window index 0 */
@@ -453,28 +478,75 @@ static void zo_parse_rle(zo_parser *z)
             full = zo_put_literal(z, z->in[p]);
             p++;
         }
-        if (full)
+        z->p = p;
+        if (full) {
             zo_cut_block(z, p, 0);
+            return ZO_EV_BLOCK;
+        }
     }
-    zo_cut_block(z, p, 1);
 }
 
 /* deflate_huff, src/deflate.c:2210-2247 (Z_HUFFMAN_ONLY): every byte a literal */
-static void zo_parse_huff(zo_parser *z)
+static int zo_run_huff(zo_parser *z)
 {
-    uint32_t p = 0;
     for (;;) {
+        uint32_t p = z->p;
         if (z->data_end - p == 0) { /* :2218 */
             zo_refill(z, p);
             if (z->data_end - p == 0)
-                break;
+                return ZO_EV_END;
         }
         int full = zo_put_literal(z, z->in[p]);
-        p++;
-        if (full)
-            zo_cut_block(z, p, 0);
+        z->p = p + 1;
+        if (full) {
+            zo_cut_block(z, p + 1, 0);
+            return ZO_EV_BLOCK;
+        }
     }
-    zo_cut_block(z, p, 1);
+}
+
+/* the parse function deflate() picks, src/deflate.c:1216-1219 */
+static int zo_run(zo_parser *z)
+{
+    if (z->strategy == 2)
+        return zo_run_huff(z);
+    if (z->strategy == 3)
+        return zo_run_rle(z);
+    return z->cfg.slow ? zo_run_lazy(z) : zo_run_greedy(z);
+}
+
+/* what the parse functions do when the input is used up and a flush was asked for, before
+ * they flush the block: the literal still owed (:2108-2112), and the strings at the very end
+ * that the next call's fill_window has to index (:2113, :1975; none for rle/huff :2195,2238) */
+static void zo_end_of_input(zo_parser *z)
+{
+    if (z->strategy != 2 && z->strategy != 3) {
+        if (z->cfg.slow && z->have_pending) {
+            (void)zo_put_literal(z, z->in[z->p - 1]);
+            z->have_pending = 0;
+        }
+        z->insert = z->p < 2 ? z->p : 2;
+    } else {
+        z->insert = 0;
+    }
+}
+
+/* a parser at the start of a stream, or after a full flush (CLEAR_HASH, strstart = 0,
+ * src/deflate.c:1244-1250); the symbol and block arrays carry on */
+static void zo_parser_restart(zo_parser *z, const uint8_t *in)
+{
+    z->in = in;
+    z->n = 0;
+    z->base = 0;
+    z->data_end = 0;
+    z->p = 0;
+    z->cur_len = 2;
+    z->cur_at = 0;
+    z->have_pending = 0;
+    z->glen = z->gat = 0;
+    z->insert = 0;
+    z->block_begin_in = 0;
+    memset(z->head, 0, ((size_t)z->hmask + 1) * sizeof(uint32_t));
 }
 
 int zo_parse(const uint8_t *in, uint32_t n, int level, int wbits, int mem_level, int strategy,
@@ -504,14 +576,11 @@ int zo_parse(const uint8_t *in, uint32_t n, int level, int wbits, int mem_level,
     }
     z.syms = syms;
     z.blocks = blocks;
-    if (strategy == 2) /* the strategy decides before the level does, src/deflate.c:1216-1219 */
-        zo_parse_huff(&z);
-    else if (strategy == 3)
-        zo_parse_rle(&z);
-    else if (z.cfg.slow)
-        zo_parse_lazy(&z);
-    else
-        zo_parse_greedy(&z);
+    z.cur_len = 2;
+    while (zo_run(&z) != ZO_EV_END) {
+    }
+    zo_end_of_input(&z);
+    zo_cut_block(&z, z.p, 1); /* FLUSH_BLOCK(s, 1), :2114-2117 */
     *nsyms = z.nsyms;
     *nblocks = z.nblocks;
     free(z.head);
@@ -809,6 +878,14 @@ static inline void zo_byte(zo_bits *w, uint8_t b)
     w->pos++;
 }
 
+/* How many bytes the reference can hand out at this point: flush_pending() first moves
+ * every complete byte of bi_buf to the pending buffer (_tr_flush_bits, src/deflate.c:933),
+ * so it is simply every whole byte written so far. */
+static uint32_t zo_produced(const zo_bits *w)
+{
+    return w->pos;
+}
+
 /* send_bits, src/trees.c:292-304: LSB-first */
 static inline void zo_put(zo_bits *w, uint32_t value, int nbits)
 {
@@ -982,6 +1059,226 @@ static void zo_emit_block(zo_bits *w, const uint8_t *in, const zo_symbol *syms, 
 #define ZO_DEFLATE_STATE_BYTES 5920u /* sizeof(deflate_state), LP64 build of the reference */
 #define ZO_INFLATE_STATE_BYTES 7152u /* sizeof(inflate_state), LP64 build of the reference */
 
+/* zsc_compress with source_len > max_block_len (src/zsc_compress.c:121-138): the wrapper
+ * hands deflate() the input in sections of max_block_len with Z_FULL_FLUSH between them --
+ * and the OUTPUT in slices of max_block_len too, refilling whichever of the two has run
+ * out before each call.  Where a section ends the stream gets the empty stored block
+ * 00 00 FF FF and the history is forgotten (src/deflate.c:1240-1252), UNLESS the output
+ * slice ran out while the section's last block was being flushed: then deflate() returns
+ * with the flush unfinished, the wrapper refills the input as well, and the next section is
+ * compressed with the history, no marker (SURVEY finding 2).  A slice that runs out in the
+ * middle of a section, when all of the section has already been read into the window, lets
+ * the next section in early in the same way.  So what is in the stream depends on where the
+ * compressed bytes fall relative to multiples of max_block_len; this function follows the
+ * calls one by one. */
+typedef struct {
+    zo_parser z;
+    zo_bits w;
+    const uint8_t *source;
+    uint32_t source_len;
+    uint32_t run_abs;      /* where the current parser's position 0 lies in source */
+    uint32_t given;        /* input handed to deflate() so far (absolute) */
+    uint32_t delivered;    /* total_out */
+    uint32_t avail_out;
+    int wrap, level, strategy, wb;
+    int header_done, finishing, trailer_done;
+    uint32_t emitted_blocks; /* blocks of z.blocks already written to w */
+} zo_stream;
+
+static void zo_s_flush_pending(zo_stream *m)
+{
+    uint32_t have = zo_produced(&m->w) - m->delivered;
+    uint32_t len = have < m->avail_out ? have : m->avail_out;
+    m->delivered += len;
+    m->avail_out -= len;
+}
+
+static void zo_s_emit_new_blocks(zo_stream *m)
+{
+    for (; m->emitted_blocks < m->z.nblocks; m->emitted_blocks++)
+        zo_emit_block(&m->w, m->z.in, m->z.syms, &m->z.blocks[m->emitted_blocks], m->strategy);
+}
+
+/* one deflate() call; returns ZO_OK, 1 (Z_STREAM_END) or ZO_BUF_ERROR */
+static int zo_s_deflate(zo_stream *m, int finish)
+{
+    zo_parser *z = &m->z;
+    if (m->avail_out == 0)
+        return ZO_BUF_ERROR; /* src/deflate.c:987-990 */
+    if (zo_produced(&m->w) != m->delivered) { /* :996-1008 */
+        zo_s_flush_pending(m);
+        if (m->avail_out == 0)
+            return ZO_OK;
+    }
+    if (!m->header_done) { /* :1029-1090 */
+        m->header_done = 1;
+        if (m->wrap == 1) {
+            uint32_t hdr = (8u + (((uint32_t)m->wb - 8u) << 4)) << 8;
+            uint32_t lf = (m->strategy >= 2 || m->level < 2) ? 0u : m->level < 6 ? 1u : m->level == 6 ? 2u : 3u;
+            hdr |= lf << 6;
+            hdr += 31 - hdr % 31;
+            zo_byte(&m->w, (uint8_t)(hdr >> 8));
+            zo_byte(&m->w, (uint8_t)hdr);
+        } else if (m->wrap == 2) {
+            static const uint8_t fixed[8] = {31, 139, 8, 0, 0, 0, 0, 0};
+            for (int i = 0; i < 8; i++)
+                zo_byte(&m->w, fixed[i]);
+            zo_byte(&m->w, m->level == 9 ? 2 : (m->strategy >= 2 || m->level < 2) ? 4 : 0);
+            zo_byte(&m->w, 3);
+        }
+        if (m->wrap) {
+            zo_s_flush_pending(m);
+            if (zo_produced(&m->w) != m->delivered)
+                return ZO_OK;
+        }
+    }
+    if (!m->finishing) { /* :1211-1260 */
+        z->n = m->given - m->run_abs;
+        for (;;) {
+            int ev = zo_run(z);
+            if (ev == ZO_EV_BLOCK) {
+                zo_s_emit_new_blocks(m); /* FLUSH_BLOCK(s, 0) */
+                zo_s_flush_pending(m);
+                if (m->avail_out == 0)
+                    return ZO_OK; /* need_more */
+                continue;
+            }
+            /* the input given so far is used up */
+            zo_end_of_input(z);
+            if (finish) {
+                zo_cut_block(z, z->p, 1);
+                zo_s_emit_new_blocks(m);
+                zo_s_flush_pending(m);
+                m->finishing = 1; /* FINISH_STATE */
+                if (m->avail_out == 0)
+                    return ZO_OK; /* finish_started */
+                break;
+            }
+            if (z->nsyms != z->block_begin_sym) { /* if (s->last_lit) FLUSH_BLOCK(s, 0) */
+                zo_cut_block(z, z->p, 0);
+                zo_s_emit_new_blocks(m);
+                zo_s_flush_pending(m);
+                if (m->avail_out == 0)
+                    return ZO_OK; /* need_more: the flush marker is never written (finding 2) */
+            }
+            /* block_done with Z_FULL_FLUSH: _tr_stored_block(s, 0, 0, 0), forget the history */
+            zo_put(&m->w, 0, 3);
+            zo_align(&m->w);
+            zo_byte(&m->w, 0);
+            zo_byte(&m->w, 0);
+            zo_byte(&m->w, 0xff);
+            zo_byte(&m->w, 0xff);
+            m->run_abs += z->p;
+            zo_parser_restart(z, m->source + m->run_abs);
+            zo_s_flush_pending(m);
+            return ZO_OK; /* whether or not avail_out is 0 (:1253-1257, :1262-1264) */
+        }
+    }
+    if (!finish)
+        return ZO_OK;
+    if (m->wrap == 0)
+        return 1;
+    if (!m->trailer_done) { /* :1270-1290 */
+        m->trailer_done = 1;
+        if (m->wrap == 1) {
+            uint32_t a = zo_adler32(1u, m->source, m->source_len);
+            zo_byte(&m->w, (uint8_t)(a >> 24));
+            zo_byte(&m->w, (uint8_t)(a >> 16));
+            zo_byte(&m->w, (uint8_t)(a >> 8));
+            zo_byte(&m->w, (uint8_t)a);
+        } else {
+            uint32_t c = zo_crc32(0u, m->source, m->source_len);
+            for (int i = 0; i < 4; i++)
+                zo_byte(&m->w, (uint8_t)(c >> (8 * i)));
+            for (int i = 0; i < 4; i++)
+                zo_byte(&m->w, (uint8_t)(m->source_len >> (8 * i)));
+        }
+        zo_s_flush_pending(m);
+        return zo_produced(&m->w) != m->delivered ? ZO_OK : 1;
+    }
+    return 1; /* wrap was negated after the trailer (:1291-1294) */
+}
+
+static int zo_compress_sections(uint8_t *dest, uint32_t *dest_len, const uint8_t *source,
+                                uint32_t source_len, uint32_t max_block_len, int level, int wrap,
+                                int wb, int mem_level, int strategy, uint32_t bound)
+{
+    const uint32_t cap_in = *dest_len;
+    zo_stream *m = (zo_stream *)calloc(1, sizeof *m);
+    /* the stream can outgrow the wrapper's own bound (5 bytes per flush marker against the
+     * 4 it allows for); the caller then gets Z_BUF_ERROR from a dest of that size, like here */
+    uint32_t scratch_cap = bound + source_len / max_block_len * 8u + (source_len >> 3) + 4096u;
+    uint8_t *scratch = (uint8_t *)malloc(scratch_cap);
+    zo_symbol *syms = (zo_symbol *)malloc(((size_t)source_len + 1) * sizeof(zo_symbol));
+    const uint32_t sym_cap = (1u << (mem_level + 6)) - 1u;
+    uint32_t max_blocks = source_len / sym_cap + source_len / max_block_len + 4;
+    zo_block *blocks = (zo_block *)malloc((size_t)max_blocks * sizeof(zo_block));
+    zo_parser *z = &m->z;
+    z->wsize = 1u << wb;
+    z->wmask = z->wsize - 1;
+    z->max_dist = z->wsize - ZO_MIN_LOOKAHEAD;
+    uint32_t hbits = (uint32_t)mem_level + 7u;
+    z->hmask = (1u << hbits) - 1;
+    z->hshift = (hbits + 2u) / 3u;
+    z->sym_cap = sym_cap;
+    z->cfg = zo_levels[level];
+    z->strategy = strategy;
+    z->head = (uint32_t *)calloc((size_t)z->hmask + 1, sizeof(uint32_t));
+    z->link = (uint32_t *)calloc(z->wsize, sizeof(uint32_t));
+    z->syms = syms;
+    z->blocks = blocks;
+    if (!m || !scratch || !syms || !blocks || !z->head || !z->link) {
+        free(scratch);
+        free(syms);
+        free(blocks);
+        free(z->head);
+        free(z->link);
+        free(m);
+        return ZO_MEM_ERROR;
+    }
+    zo_parser_restart(z, source);
+    m->w.out = scratch;
+    m->w.cap = scratch_cap;
+    m->source = source;
+    m->source_len = source_len;
+    m->wrap = wrap;
+    m->level = level;
+    m->strategy = strategy;
+    m->wb = wb;
+
+    /* the wrapper's loop, src/zsc_compress.c:121-138 */
+    uint32_t left_dest = cap_in, left_src = source_len;
+    int err = ZO_OK;
+    while (err == ZO_OK) {
+        if (m->avail_out == 0) {
+            m->avail_out = left_dest < max_block_len ? left_dest : max_block_len;
+            left_dest -= m->avail_out;
+        }
+        /* avail_in == 0: everything given so far has been read into the window */
+        if (m->run_abs + z->data_end == m->given) {
+            uint32_t take = left_src < max_block_len ? left_src : max_block_len;
+            m->given += take;
+            left_src -= take;
+        }
+        err = zo_s_deflate(m, left_src == 0);
+    }
+    uint32_t give = m->delivered;
+    if (!m->w.overflow)
+        memcpy(dest, scratch, give);
+    *dest_len = give;
+    int rc = err == 1 ? ZO_OK : err;
+    if (m->w.overflow)
+        rc = ZO_MEM_ERROR;
+    free(scratch);
+    free(syms);
+    free(blocks);
+    free(z->head);
+    free(z->link);
+    free(m);
+    return rc;
+}
+
+
 int zo_compress(uint8_t *dest, uint32_t *dest_len, const uint8_t *source, uint32_t source_len,
                 uint32_t max_block_len, uint32_t work_len, int level, int window_bits,
                 int mem_level, int strategy, int *unsupported)
@@ -1008,7 +1305,7 @@ int zo_compress(uint8_t *dest, uint32_t *dest_len, const uint8_t *source, uint32
     if (wb == 8)
         wb = 9;
 
-    if (max_block_len == 0 || source_len > max_block_len || level == 0) {
+    if (max_block_len == 0 || level == 0) {
         *unsupported = 1;
         return ZO_STREAM_ERROR;
     }
@@ -1017,6 +1314,11 @@ int zo_compress(uint8_t *dest, uint32_t *dest_len, const uint8_t *source, uint32
     err = zo_compress_max_output(source_len, max_block_len, level, window_bits, mem_level, &bound);
     if (err != ZO_OK)
         return err;
+    if (source_len > max_block_len) {
+        *dest_len = cap_in;
+        return zo_compress_sections(dest, dest_len, source, source_len, max_block_len, level, wrap, wb,
+                                    mem_level, strategy, bound);
+    }
 
     /* stages P, H+E into a scratch stream of the worst-case size */
     uint32_t scratch_cap = bound + 64;

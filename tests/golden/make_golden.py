@@ -197,6 +197,19 @@ def main():
         sections.append({"kind": "text", "size": 300000, "seed": 9, "max_block_len": mbl, "rc": rc,
                          "out_len": len(out), "out_sha256": sha(out),
                          "markers": out.count(b"\x00\x00\xff\xff")})
+    for kind, size, seed, mbl, lvl, wb, st, cap in (
+            ("table", 140000, 3, 10000, 6, 15, 0, None), ("bitmap", 200000, 4, 32768, 9, 31, 0, None),
+            ("random", 70000, 5, 4096, 6, 15, 0, None), ("zero", 100000, 6, 1000, 6, -15, 0, None),
+            ("runs", 90000, 7, 7777, 1, 15, 3, None), ("text", 50000, 8, 300, 3, 15, 0, None),
+            ("object", 120000, 9, 65536, 4, 31, 1, None), ("text", 80000, 10, 5000, 6, 15, 2, None),
+            ("text", 80000, 11, 5000, 6, 15, 0, 20000), ("random", 30000, 12, 100, 6, 31, 0, None)):
+        d4 = corpus.make_buffer(kind, size, seed)
+        rc, out = R.compress(d4, lvl, window_bits=wb, strategy=st, max_block_len=mbl, dest_cap=cap)
+        sections.append({"kind": kind, "size": size, "seed": seed, "max_block_len": mbl, "level": lvl,
+                         "window_bits": wb, "strategy": st, "dest_cap": cap, "rc": rc,
+                         "out_len": len(out), "out_sha256": sha(out),
+                         "markers": out.count(b"\x00\x00\xff\xff"),
+                         "boundaries": (size - 1) // mbl})
     # checksums
     sums = []
     for n in (0, 1, 15, 16, 17, 5551, 5552, 5553, 11105, 65536, 150001):
