@@ -314,7 +314,7 @@ extern "C" int emu_uncompress(const uint8_t *src, uint32_t n, int window_bits, u
     InfLds *lds = (InfLds *)malloc(sizeof(InfLds));
     memset(lds, 0x3C, sizeof(InfLds));
     InfResult res;
-    inflate_stream(job, lds, &res);
+    inflate_with_resync(job, lds, &res);
     free(lds);
     *out_len = res.out_len;
     *consumed = res.consumed;

@@ -49,6 +49,13 @@ typedef struct {
     CkLds ck;
 } InfLds;
 
+/* where decoding goes on after an inflateSync: the stream is inflated again from there */
+typedef struct {
+    uint32_t state;  /* 0 not started, 1 a data error happened: resynchronise and go on, 2 finished */
+    uint32_t out_pos, errors, gzip;
+    uint32_t sy_lo, sy_hi, sy_rb; /* what the reference's bit buffer held at the error */
+} InfResume;
+
 typedef struct {
     const uint8_t *src;
     uint32_t n;
@@ -129,8 +136,61 @@ DEV int inf_build(InfCode *c, const uint16_t *lens, int n, int kind)
     return (int)c->count[0] - 1;
 }
 
+/* inflateSync's search (reference src/inflate.c:1523-1604) for the whole wave: the first
+ * 00 00 FF FF in what the reference's bit buffer holds at the error (sy_rb bits of the stream
+ * from bit sy_start, after its "hold <<= bits & 7") followed by the input from byte nin on.
+ * Returns the number of input bytes up to the end of the pattern, or 0xffffffff when there
+ * is none. */
+DEV uint32_t inf_sync_search(const uint8_t *src, uint32_t n, uint64_t sy_start, uint32_t sy_rb,
+                                      uint32_t nin)
+{
+    uint32_t hold = 0;
+    for (uint32_t k = 0; k < sy_rb; k += 8u) {
+        const uint64_t bit = sy_start + k;
+        const uint32_t by = (uint32_t)(bit >> 3), sh = (uint32_t)(bit & 7u);
+        uint32_t two = UNI(src[by]);
+        if (sh && by + 1u < n)
+            two |= UNI(src[by + 1u]) << 8;
+        hold |= ((two >> sh) & 0xffu) << k;
+    }
+    if (sy_rb < 32u)
+        hold &= (1u << sy_rb) - 1u;
+    uint32_t rb = sy_rb;
+    hold <<= rb & 7u; /* sic, :1571 */
+    rb -= rb & 7u;
+    const uint32_t nh = rb >> 3; /* bytes of hold searched before the input */
+    const uint32_t vlen = nh + (n - nin);
+    for (uint32_t base = 0; base + 4u <= vlen; base += WAVE) {
+        LANEVAR(int, _hit);
+        FOR_LANES
+        {
+            const uint32_t m = base + (uint32_t)LANE;
+            int ok = m + 4u <= vlen;
+            for (uint32_t j = 0; j < 4u && ok; j++) {
+                const uint32_t i = m + j;
+                const uint32_t c = i < nh ? (hold >> (8u * i)) & 0xffu : src[nin + (i - nh)];
+                ok = c == (j < 2u ? 0u : 0xffu);
+            }
+            LV(_hit) = ok;
+        }
+        const uint64_t hm = BALLOT(_hit);
+        if (hm != 0) {
+            const uint32_t found = base + (uint32_t)CTZ64(hm);
+            return found + 4u > nh ? found + 4u - nh : 0u;
+        }
+    }
+    return 0xffffffffu;
+}
+
 /* the whole stream; mirrors zsc_uncompress_gzip2 with gz_head == NULL */
-DEV void inflate_stream(const InfJob &job, InfLds *lds, InfResult *res)
+/* One inflate() call of zsc_uncompress's loop (reference src/zsc_uncompr.c:104-125): decodes
+ * until the stream ends or fails.  Returns 1 after a data error: *rs then holds what
+ * inflateSync needs, and the stream is entered once more -- inflateSync's search for the
+ * next flush marker first, then decoding from there -- by another launch of the kernel, not
+ * by a loop in here: wrapping the decoder in an outer loop doubles its register count (135
+ * instead of 68 VGPRs, occupancy 3 instead of 7), and even the search alone, placed after the
+ * decode loop, costs it a wave per SIMD; the sound streams would pay for the damaged ones. */
+DEV int inflate_stream(const InfJob &job, InfLds *lds, InfResult *res, InfResume *rs)
 {
     const uint8_t *src = job.src;
     const uint32_t n = job.n, cap = job.cap;
@@ -167,6 +227,7 @@ DEV void inflate_stream(const InfJob &job, InfLds *lds, InfResult *res)
         LV(cur) = v;
     }
 
+    const int resumed = UNI(rs->state) == 1u;
     uint32_t pos = 0, flushed = 0; /* output bytes produced / stored to dst */
     uint32_t dmax = 32768u;
     int gzip = 0;
@@ -306,9 +367,7 @@ DEV void inflate_stream(const InfJob &job, InfLds *lds, InfResult *res)
             break;                                                                            \
         }                                                                                     \
         const uint32_t _peek = (uint32_t)br.hold & 0x7fffu;                                   \
-        uint32_t _r = 0; /* the 15 bits MSB first */                                          \
-        for (int _b = 0; _b < 15; _b++)                                                       \
-            _r |= ((_peek >> _b) & 1u) << (14 - _b);                                          \
+        const uint32_t _r = BREV32(_peek) >> 17; /* the 15 bits MSB first */                  \
         LANEVAR(int, _hit);                                                                   \
         FOR_LANES                                                                             \
         {                                                                                     \
@@ -343,12 +402,82 @@ DEV void inflate_stream(const InfJob &job, InfLds *lds, InfResult *res)
         br.used += _len;                                                                      \
     } while (0)
 
+/* The same for the two codes of the symbol loop, with each length's first code, count and
+ * symbol offset held by lane `length` in registers (FC = first | count << 16, OF = offs):
+ * one LDS read per symbol instead of five. */
+#define INF_DECODE_R(C, FC, OF, MAXLEN, EMPTY, OUTSYM)                                         \
+    do {                                                                                      \
+        if (br.bits < 15)                                                                     \
+            INF_REFILL();                                                                     \
+        if (EMPTY) {                                                                          \
+            INF_NEED(1);                                                                      \
+            uint32_t _d1;                                                                     \
+            INF_TAKE(_d1, 1);                                                                 \
+            (void)_d1;                                                                        \
+            (OUTSYM) = -2;                                                                    \
+            break;                                                                            \
+        }                                                                                     \
+        const uint32_t _peek = (uint32_t)br.hold & 0x7fffu;                                   \
+        const uint32_t _r = BREV32(_peek) >> 17; /* the 15 bits MSB first */                  \
+        LANEVAR(int, _hit);                                                                   \
+        FOR_LANES                                                                             \
+        {                                                                                     \
+            const uint32_t _l = (uint32_t)LANE;                                               \
+            const uint32_t _c = _r >> ((15u - _l) & 31u);                                     \
+            LV(_hit) = _l >= 1u && _l <= (MAXLEN) &&                                          \
+                       (uint32_t)(_c - (LV(FC) & 0xffffu)) < (LV(FC) >> 16);                  \
+        }                                                                                     \
+        const uint64_t _m = BALLOT(_hit);                                                     \
+        if (_m == 0) {                                                                        \
+            INF_NEED(MAXLEN);                                                                 \
+            uint32_t _d;                                                                      \
+            INF_TAKE(_d, MAXLEN);                                                             \
+            (void)_d;                                                                         \
+            (OUTSYM) = -2;                                                                    \
+            break;                                                                            \
+        }                                                                                     \
+        const uint32_t _len = (uint32_t)CTZ64(_m);                                            \
+        if (br.bits < _len) {                                                                 \
+            exhausted = 1;                                                                    \
+            rc = INF_BUF;                                                                     \
+            goto done;                                                                        \
+        }                                                                                     \
+        const uint32_t _code = _r >> (15 - _len);                                             \
+        (OUTSYM) = (int)UNI((C)->sym[READLANE(OF, _len) + (_code - (READLANE(FC, _len) & 0xffffu))]); \
+        br.hold >>= _len;                                                                     \
+        br.bits -= _len;                                                                      \
+        br.used += _len;                                                                      \
+    } while (0)
+
     /* HEAD .. HCRC, reference src/inflate.c:740-954 */
     if (wb && (wb < 8 || wb > 15)) {
         rc = -2;
         goto done;
     }
-    if (wrap) {
+    if (resumed) {
+        /* zsc_uncompress answers Z_DATA_ERROR with inflateSync (src/zsc_uncompr.c:109-125,
+         * src/inflate.c:1547-1604): find the next 00 00 FF FF -- first in what was left of the
+         * bit buffer, then in the input -- and decode on from there as a raw stream: mode =
+         * TYPE, empty window, the totals and the check value carry on */
+        pos = flushed = out_base = UNI(rs->out_pos);
+        data_errors = UNI(rs->errors);
+        gzip = (int)UNI(rs->gzip);
+        const uint64_t sy0 = ((uint64_t)UNI(rs->sy_hi) << 32) | UNI(rs->sy_lo);
+        const uint32_t rb0 = UNI(rs->sy_rb);
+        const uint32_t nin = (uint32_t)((sy0 + rb0) >> 3); /* the reference's next_in */
+        if (nin >= n && rb0 < 8u) {                         /* :1562-1565 */
+            rc = INF_BUF;
+            INF_SEEK(n < nin ? n : nin);
+            goto done;
+        }
+        const uint32_t taken = inf_sync_search(src, n, sy0, rb0, nin);
+        if (taken == 0xffffffffu) {
+            rc = INF_DATA; /* the search used up all the input (:1585-1593) */
+            INF_SEEK(n);
+            goto done;
+        }
+        INF_SEEK(nin + taken);
+    } else if (wrap) {
         INF_NEED(16);
         const uint32_t hw = (uint32_t)br.hold & 0xffffu;
         if ((wrap & 2) && hw == 0x8b1fu) {
@@ -417,7 +546,6 @@ DEV void inflate_stream(const InfJob &job, InfLds *lds, InfResult *res)
     }
 
     /* blocks */
-blocks:
     for (;;) {
         uint32_t last, type;
         INF_NEED(3);
@@ -556,9 +684,24 @@ blocks:
                     INF_BAD;
             }
             /* symbols */
+            WAVE_SYNC();
+            LANEVAR(uint32_t, lfc);
+            LANEVAR(uint32_t, lof);
+            LANEVAR(uint32_t, dfc);
+            LANEVAR(uint32_t, dof);
+            FOR_LANES
+            {
+                const int l = LANE & 15;
+                LV(lfc) = (uint32_t)lds->lit.first[l] | ((uint32_t)lds->lit.count[l] << 16);
+                LV(lof) = lds->lit.offs[l];
+                LV(dfc) = (uint32_t)lds->dist.first[l] | ((uint32_t)lds->dist.count[l] << 16);
+                LV(dof) = lds->dist.offs[l];
+            }
+            const uint32_t lmax = UNI(lds->lit.max_len), lempty = UNI(lds->lit.empty);
+            const uint32_t dmaxlen = UNI(lds->dist.max_len), dempty = UNI(lds->dist.empty);
             for (;;) {
                 int sym;
-                INF_DECODE(&lds->lit, sym);
+                INF_DECODE_R(&lds->lit, lfc, lof, lmax, lempty, sym);
                 if (sym == -2)
                     INF_BAD;
                 if (sym < 256) {
@@ -583,7 +726,7 @@ blocks:
                 INF_TAKE(ex, xb);
                 len = c < 8 ? c + 3u : c == 28 ? 258u : ((4u + ((c - 4u) & 3u)) << ((c - 4u) >> 2)) + 3u + ex;
                 int ds;
-                INF_DECODE(&lds->dist, ds);
+                INF_DECODE_R(&lds->dist, dfc, dof, dmaxlen, dempty, ds);
                 if (ds < 0 || ds > 29)
                     INF_BAD;
                 xb = ds < 4 ? 0u : ((uint32_t)ds >> 1) - 1u;
@@ -661,65 +804,21 @@ blocks:
     }
 
 bad:
-    /* zsc_uncompress answers Z_DATA_ERROR with inflateSync (src/zsc_uncompr.c:109-125,
-     * src/inflate.c:1547-1604): find the next 00 00 FF FF -- first in what is left of the bit
-     * buffer, then in the input -- and decode on from there as a raw stream. */
+    /* a data error: hand the state inflateSync starts from to the next entry */
     data_errors++;
     INF_FLUSH(1);
+    ON_LANE0
     {
-        const uint32_t nin = (uint32_t)((sy_start + sy_rb) >> 3); /* the reference's next_in */
-        if (nin >= n && sy_rb < 8u) {                              /* :1562-1565 */
-            rc = INF_BUF;
-            INF_SEEK(n < nin ? n : nin);
-            goto done;
-        }
-        /* hold: sy_rb bits of the stream from bit sy_start, then "hold <<= bits & 7" (sic) */
-        uint32_t hold = 0;
-        for (uint32_t k = 0; k < sy_rb; k += 8u) {
-            const uint64_t bit = sy_start + k;
-            const uint32_t by = (uint32_t)(bit >> 3), sh = (uint32_t)(bit & 7u);
-            uint32_t two = UNI(src[by]);
-            if (sh && by + 1u < n)
-                two |= UNI(src[by + 1u]) << 8;
-            hold |= ((two >> sh) & 0xffu) << k;
-        }
-        if (sy_rb < 32u)
-            hold &= (1u << sy_rb) - 1u;
-        uint32_t rb = sy_rb;
-        hold <<= rb & 7u;
-        rb -= rb & 7u;
-        const uint32_t nh = rb >> 3; /* bytes of hold searched before the input */
-        /* first occurrence of the pattern in hold-bytes ++ input[nin..n) */
-        const uint32_t vlen = nh + (n - nin);
-        uint32_t found = 0xffffffffu;
-        for (uint32_t base = 0; base + 4u <= vlen && found == 0xffffffffu; base += WAVE) {
-            LANEVAR(int, _hit);
-            FOR_LANES
-            {
-                const uint32_t m = base + (uint32_t)LANE;
-                int ok = m + 4u <= vlen;
-                for (uint32_t j = 0; j < 4u && ok; j++) {
-                    const uint32_t i = m + j;
-                    const uint32_t c = i < nh ? (hold >> (8u * i)) & 0xffu : src[nin + (i - nh)];
-                    ok = c == (j < 2u ? 0u : 0xffu);
-                }
-                LV(_hit) = ok;
-            }
-            const uint64_t hm = BALLOT(_hit);
-            if (hm != 0)
-                found = base + (uint32_t)CTZ64(hm);
-        }
-        if (found == 0xffffffffu) {
-            rc = INF_DATA; /* the search used up all the input (:1585-1593) */
-            INF_SEEK(n);
-            goto done;
-        }
-        const uint32_t taken = found + 4u > nh ? found + 4u - nh : 0u; /* input bytes up to the end of the pattern */
-        INF_SEEK(nin + taken);
-        out_base = pos; /* inflateReset: empty window, mode = TYPE */
-        dmax = 32768u;
-        goto blocks;
+        rs->state = 1;
+        rs->out_pos = pos;
+        rs->errors = data_errors;
+        rs->gzip = (uint32_t)gzip;
+        rs->sy_lo = (uint32_t)sy_start;
+        rs->sy_hi = (uint32_t)(sy_start >> 32);
+        rs->sy_rb = sy_rb;
     }
+    WAVE_SYNC();
+    return 1;
 
 done:
     INF_FLUSH(1);
@@ -732,7 +831,9 @@ done:
         res->out_len = rc == INF_NEED_DICT ? 0u : pos;
         res->consumed = rc == INF_NEED_DICT ? 0u : used_bytes;
         res->pad = fail_line;
+        rs->state = 2;
     }
+    return 0;
 #undef INF_REFILL
 #undef INF_NEED
 #undef INF_TAKE
@@ -741,6 +842,21 @@ done:
 #undef INF_SEEK
 #undef INF_FLUSH
 #undef INF_DECODE
+#undef INF_DECODE_R
+}
+
+
+/* zsc_uncompress for one stream on the host emulation: inflate again after every recovered
+ * data error (the GPU runtime relaunches the kernel instead, see inflate_stream) */
+DEV void inflate_with_resync(const InfJob &job, InfLds *lds, InfResult *res)
+{
+    InfResume rs;
+    rs.state = 0;
+    rs.out_pos = rs.errors = rs.gzip = rs.sy_lo = rs.sy_hi = rs.sy_rb = 0;
+    for (uint32_t round = 0; round < job.n / 4u + 2u; round++) {
+        if (!inflate_stream(job, lds, res, &rs))
+            return;
+    }
 }
 
 #endif

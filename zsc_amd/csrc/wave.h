@@ -33,6 +33,7 @@
 #include <string.h>
 
 #define DEV static inline
+#define DEV_OUTLINED static /* rare paths kept out of the caller's register budget on the GPU */
 #define GLOBAL_FN static
 #define LDS_DECL(T, name, n) T name[n]
 #define LANEVAR(T, name) T name[WAVE]
@@ -100,6 +101,15 @@ static inline uint32_t ld_u16(const uint8_t *p)
 #define POPC64(x) __builtin_popcountll(x)
 #define CLZ64(x) __builtin_clzll(x)
 #define CLZ32(x) __builtin_clz(x)
+static inline uint32_t emu_brev32(uint32_t v)
+{
+    v = ((v >> 1) & 0x55555555u) | ((v & 0x55555555u) << 1);
+    v = ((v >> 2) & 0x33333333u) | ((v & 0x33333333u) << 2);
+    v = ((v >> 4) & 0x0f0f0f0fu) | ((v & 0x0f0f0f0fu) << 4);
+    v = ((v >> 8) & 0x00ff00ffu) | ((v & 0x00ff00ffu) << 8);
+    return (v >> 16) | (v << 16);
+}
+#define BREV32(x) emu_brev32(x)
 #define COPY16(dst, src) memcpy((dst), (src), 16)
 #define UNI(x) (x)
 
@@ -108,6 +118,7 @@ static inline uint32_t ld_u16(const uint8_t *p)
 #include <hip/hip_runtime.h>
 
 #define DEV __device__ __forceinline__
+#define DEV_OUTLINED __device__ __noinline__
 #define GLOBAL_FN __global__
 #define LDS_DECL(T, name, n) __shared__ T name[n]
 #define LANEVAR(T, name) T name
@@ -177,6 +188,7 @@ DEV uint32_t ld_u16(const uint8_t *p)
 #define POPC64(x) __builtin_popcountll(x)
 #define CLZ64(x) __builtin_clzll(x)
 #define CLZ32(x) __builtin_clz(x)
+#define BREV32(x) __builtin_bitreverse32(x)
 /* A value that is the same in every lane but was produced by a vector instruction
  * (an LDS or global load from a wave-uniform address): move it to an SGPR, so that
  * branches on it are scalar branches instead of exec-mask regions and arithmetic on

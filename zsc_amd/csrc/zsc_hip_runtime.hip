@@ -360,17 +360,21 @@ typedef struct {
 } ZdInfItem;
 
 /* kernel 5: one wavefront per compressed stream */
-__global__ __launch_bounds__(64) void k_inflate(const uint8_t *__restrict__ src,
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(7, 8))) void k_inflate(const uint8_t *__restrict__ src,
                                                 uint8_t *__restrict__ dst,
                                                 const ZdInfItem *__restrict__ items,
                                                 const uint32_t *__restrict__ order,
-                                                InfResult *__restrict__ res, int32_t window_bits,
+                                                InfResult *__restrict__ res,
+                                                InfResume *__restrict__ resume,
+                                                uint32_t *__restrict__ pending, int32_t window_bits,
                                                 uint32_t count)
 {
     __shared__ InfLds lds;
     if (blockIdx.x >= count)
         return;
     const uint32_t i = order[blockIdx.x];
+    if (resume[i].state == 2u)
+        return; /* finished in an earlier launch (only streams that resynchronise come back) */
     const ZdInfItem it = items[i];
     InfJob job;
     job.src = src + it.src_off;
@@ -378,7 +382,10 @@ __global__ __launch_bounds__(64) void k_inflate(const uint8_t *__restrict__ src,
     job.dst = dst + it.dst_off;
     job.cap = it.dst_cap;
     job.window_bits = window_bits;
-    inflate_stream(job, &lds, &res[i]);
+    if (inflate_stream(job, &lds, &res[i], &resume[i])) {
+        if ((threadIdx.x & 63) == 0)
+            atomicAdd(pending, 1u); /* the host launches once more for these */
+    }
 }
 
 /* ------------------------------------------------------------------------ */
@@ -1015,7 +1022,9 @@ extern "C" ZlibReturn zsc_hip_compress_batch(U32 count, const U8 *const *sources
 struct zsc_hip_inflate_plan {
     uint32_t count = 0;
     int32_t window_bits = 15;
-    DevBuf d_items, d_order, d_res;
+    DevBuf d_items, d_order, d_res, d_resume, d_pending;
+    const void *last_src = nullptr;
+    void *last_dst = nullptr;
     hipStream_t last_stream = nullptr;
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
     bool timed = false;
@@ -1047,7 +1056,8 @@ extern "C" ZlibReturn zsc_hip_inflate_plan_create(zsc_hip_inflate_plan **plan_ou
                      [&](uint32_t a, uint32_t b) { return items[a].dst_cap > items[b].dst_cap; });
     bool ok = pl->d_items.ensure(sizeof(ZdInfItem) * std::max(1u, count)) &&
               pl->d_order.ensure(4ull * std::max(1u, count)) &&
-              pl->d_res.ensure(sizeof(InfResult) * std::max(1u, count));
+              pl->d_res.ensure(sizeof(InfResult) * std::max(1u, count)) &&
+              pl->d_resume.ensure(sizeof(InfResume) * std::max(1u, count)) && pl->d_pending.ensure(4);
     if (ok && count) {
         ok = hipMemcpy(pl->d_items.p, items.data(), sizeof(ZdInfItem) * count,
                        hipMemcpyHostToDevice) == hipSuccess &&
@@ -1058,6 +1068,8 @@ extern "C" ZlibReturn zsc_hip_inflate_plan_create(zsc_hip_inflate_plan **plan_ou
         pl->d_items.release();
         pl->d_order.release();
         pl->d_res.release();
+        pl->d_resume.release();
+        pl->d_pending.release();
         delete pl;
         return Z_MEM_ERROR;
     }
@@ -1075,10 +1087,15 @@ extern "C" ZlibReturn zsc_hip_inflate_plan_run(zsc_hip_inflate_plan *pl, const v
     pl->last_stream = st;
     if (pl->count == 0)
         return Z_OK;
+    pl->last_src = d_src;
+    pl->last_dst = d_dst;
+    HIP_TRY(hipMemsetAsync(pl->d_resume.p, 0, sizeof(InfResume) * pl->count, st), return Z_STREAM_ERROR);
+    HIP_TRY(hipMemsetAsync(pl->d_pending.p, 0, 4, st), return Z_STREAM_ERROR);
     (void)hipEventRecord(pl->ev0, st);
     hipLaunchKernelGGL(k_inflate, dim3(pl->count), dim3(64), 0, st, (const uint8_t *)d_src,
                        (uint8_t *)d_dst, (const ZdInfItem *)pl->d_items.p,
-                       (const uint32_t *)pl->d_order.p, (InfResult *)pl->d_res.p, pl->window_bits,
+                       (const uint32_t *)pl->d_order.p, (InfResult *)pl->d_res.p,
+                       (InfResume *)pl->d_resume.p, (uint32_t *)pl->d_pending.p, pl->window_bits,
                        pl->count);
     (void)hipEventRecord(pl->ev1, st);
     pl->timed = true;
@@ -1091,6 +1108,22 @@ extern "C" ZlibReturn zsc_hip_inflate_plan_results(zsc_hip_inflate_plan *pl, U32
 {
     ZSC_ASSERT(pl != Z_NULL);
     HIP_TRY(hipStreamSynchronize(pl->last_stream), return Z_STREAM_ERROR);
+    /* streams that hit a data error and found a flush marker behind it (inflateSync) are
+     * inflated again from there, as zsc_uncompress's loop does (src/zsc_uncompr.c:104-125);
+     * every round consumes at least the marker, so this ends */
+    for (uint32_t round = 0; pl->count && pl->last_dst; round++) {
+        uint32_t pending = 0;
+        HIP_TRY(hipMemcpy(&pending, pl->d_pending.p, 4, hipMemcpyDeviceToHost), return Z_STREAM_ERROR);
+        if (pending == 0 || round > (1u << 30))
+            break;
+        HIP_TRY(hipMemsetAsync(pl->d_pending.p, 0, 4, pl->last_stream), return Z_STREAM_ERROR);
+        hipLaunchKernelGGL(k_inflate, dim3(pl->count), dim3(64), 0, pl->last_stream,
+                           (const uint8_t *)pl->last_src, (uint8_t *)pl->last_dst,
+                           (const ZdInfItem *)pl->d_items.p, (const uint32_t *)pl->d_order.p,
+                           (InfResult *)pl->d_res.p, (InfResume *)pl->d_resume.p,
+                           (uint32_t *)pl->d_pending.p, pl->window_bits, pl->count);
+        HIP_TRY(hipStreamSynchronize(pl->last_stream), return Z_STREAM_ERROR);
+    }
     std::vector<InfResult> res(pl->count);
     if (pl->count)
         HIP_TRY(hipMemcpy(res.data(), pl->d_res.p, sizeof(InfResult) * pl->count,
@@ -1121,6 +1154,8 @@ extern "C" void zsc_hip_inflate_plan_destroy(zsc_hip_inflate_plan *pl)
     pl->d_items.release();
     pl->d_order.release();
     pl->d_res.release();
+    pl->d_resume.release();
+    pl->d_pending.release();
     if (pl->ev0)
         (void)hipEventDestroy(pl->ev0);
     if (pl->ev1)
