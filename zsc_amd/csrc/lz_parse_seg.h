@@ -3,32 +3,34 @@
  *
  * The lazy parse (reference deflate_slow, src/deflate.c:1989-2122) is serial, and its
  * 32 KiB window has to sit in LDS, so a wave-per-buffer kernel gets four waves onto a
- * CU and is bound by single-wave latency.  This kernel shares one window between
- * SG_W waves of a workgroup and lets every wave parse its own 1 KiB segment of the
- * same buffer at the same time -- speculatively, because the state the serial parse
- * would arrive in at the start of a segment is not known yet:
+ * CU and is bound by single-wave latency.  This kernel shares one window between the
+ * SG_W waves of a workgroup.  The buffer advances in super-steps of SG_SPAN positions,
+ * cut into segments of SG_G positions that the waves take from a work queue in LDS, last
+ * segment first, and parse at the same time -- speculatively, because the state the
+ * serial parse would arrive in at the start of a segment is not known yet:
  *
  *   - hash chains do not depend on the parse at levels 4-9 (every position is
  *     inserted, src/deflate.c:2018,2069-2075), and the window base is a function
  *     of the position alone, so a parser that stands at position x with NO match
  *     pending ("fresh": match_available == 0, match_length == 2) continues
  *     identically whatever happened before x;
- *   - wave k starts fresh at its segment start and records every position it
- *     visits fresh (a bitmap in LDS, plus its token count there);
- *   - wave k-1, the only one whose start is known to be right, keeps parsing past
- *     its segment end until it is fresh at a position wave k also visited fresh:
- *     from there on wave k's tokens ARE the serial parse's tokens.  Text resyncs
- *     within a few tokens;
- *   - if no common position turns up within SG_OV bytes (a long run, say), wave k-1
- *     stops with its exact state and wave k parses its segment again from that
- *     state -- the super-step degrades towards the serial parse, never to a
- *     different result.
+ *   - every segment's parser starts fresh at the segment start and records every
+ *     position it visits fresh (a bitmap in LDS, plus its token count there);
+ *   - a parser keeps going past the end of its segment until it is fresh at a position
+ *     the parser of the segment it has run into also visited fresh: from there on that
+ *     parser's tokens ARE the serial parse's tokens.  Text resyncs within a few tokens;
+ *   - if no common position turns up within SG_OV bytes (a long run, say), the parser
+ *     stops with its exact state, and once the chain of hand-overs has reached it wave
+ *     0 parses on from that state (a redo round) -- the super-step degrades towards
+ *     the serial parse, never to a different result.
  *
- * After each super-step (SG_W segments) wave 0 walks the chain of hand-overs and
+ * After the parse phase wave 0 walks the chain of hand-overs from segment 0 (whose
+ * start state is the true one, carried over from the previous super-step) and
  * appends the valid token ranges to the buffer's symbol stream, cutting blocks
- * every 16 383 symbols exactly as _tr_tally does (include/zsc/deflate.h:338-354).
+ * every lit_bufsize-1 symbols exactly as _tr_tally does (include/zsc/deflate.h:338-354).
  * The symbol stream, block records and therefore every later kernel and the final
- * bytes are identical to the wave-per-buffer parser's.
+ * bytes are identical to the wave-per-buffer parser's.  The search itself is described
+ * further down (SG_EVAL, SG_SWEEP).
  */
 #ifndef ZSC_LZ_PARSE_SEG_H
 #define ZSC_LZ_PARSE_SEG_H
