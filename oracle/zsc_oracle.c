@@ -1083,6 +1083,11 @@ typedef struct {
     int wrap, level, strategy, wb;
     int header_done, finishing, trailer_done;
     uint32_t emitted_blocks; /* blocks of z.blocks already written to w */
+    /* level 0 (deflate_stored, src/deflate.c:1679-1880): positions in the window and in the input */
+    uint32_t st_strstart, st_block_start; /* s->strstart, s->block_start */
+    uint32_t st_read;                     /* input bytes taken from next_in so far (absolute) */
+    uint32_t st_emit;                     /* input bytes written into stored blocks so far (absolute) */
+    uint32_t pending_buf_size;
 } zo_stream;
 
 static void zo_s_flush_pending(zo_stream *m)
@@ -1097,6 +1102,100 @@ static void zo_s_emit_new_blocks(zo_stream *m)
 {
     for (; m->emitted_blocks < m->z.nblocks; m->emitted_blocks++)
         zo_emit_block(&m->w, m->z.in, m->z.syms, &m->z.blocks[m->emitted_blocks], m->strategy);
+}
+
+/* one stored block: 3 header bits, byte alignment, LEN, NLEN, the bytes (src/trees.c:838-849) */
+static void zo_s_stored_block(zo_stream *m, uint32_t len, int last)
+{
+    zo_put(&m->w, (uint32_t)last, 3);
+    zo_align(&m->w);
+    zo_byte(&m->w, (uint8_t)len);
+    zo_byte(&m->w, (uint8_t)(len >> 8));
+    zo_byte(&m->w, (uint8_t)~len);
+    zo_byte(&m->w, (uint8_t)(~len >> 8));
+    for (uint32_t i = 0; i < len; i++)
+        zo_byte(&m->w, m->source[m->st_emit + i]);
+    m->st_emit += len;
+}
+
+/* deflate_stored, src/deflate.c:1679-1880, for level 0.  Returns 0 need_more, 1 block_done,
+ * 2 finish_started, 3 finish_done.  Block lengths depend on the output space of the moment,
+ * so this follows the reference's arithmetic step by step; which bytes go where is simple:
+ * the input, in order, st_emit being the next byte to be stored. */
+static int zo_s_deflate_stored(zo_stream *m, int finish)
+{
+    const uint32_t w_size = m->z.wsize, window_size = 2u * w_size;
+    uint32_t min_block = m->pending_buf_size - 5u < w_size ? m->pending_buf_size - 5u : w_size;
+    uint32_t avail_in = m->given - m->st_read;
+    const uint32_t used0 = avail_in;
+    uint32_t len, left, have;
+    int last = 0;
+    do {
+        len = 65535u;
+        have = 5u; /* (bi_valid + 42) >> 3 with an empty bit buffer */
+        if (m->avail_out < have)
+            break;
+        have = m->avail_out - have;
+        left = m->st_strstart - m->st_block_start;
+        if (len > left + avail_in)
+            len = left + avail_in;
+        if (len > have)
+            len = have;
+        if (len < min_block && ((len == 0 && !finish) || len != left + avail_in))
+            break; /* flush is never Z_NO_FLUSH here */
+        last = finish && len == left + avail_in;
+        /* header through the pending buffer, bytes straight to next_out (:1745-1775) */
+        uint32_t from_window = left < len ? left : len;
+        zo_s_stored_block(m, len, last);
+        m->st_block_start += from_window;
+        m->st_read += len - from_window;
+        avail_in -= len - from_window;
+        m->delivered += 5u + len;
+        m->avail_out -= 5u + len;
+    } while (!last);
+
+    uint32_t used = used0 - avail_in; /* input bytes copied directly */
+    if (used) {
+        if (used >= w_size) {
+            m->st_strstart = w_size;
+        } else {
+            if (window_size - m->st_strstart <= used)
+                m->st_strstart -= w_size;
+            m->st_strstart += used;
+        }
+        m->st_block_start = m->st_strstart;
+    }
+    if (last)
+        return 3;
+    if (!finish && avail_in == 0 && m->st_strstart == m->st_block_start)
+        return 1;
+
+    /* fill the window with any remaining input (:1822-1843) */
+    have = window_size - m->st_strstart - 1u;
+    if (avail_in > have && m->st_block_start >= w_size) {
+        m->st_block_start -= w_size;
+        m->st_strstart -= w_size;
+        have += w_size;
+    }
+    if (have > avail_in)
+        have = avail_in;
+    if (have) {
+        m->st_read += have;
+        avail_in -= have;
+        m->st_strstart += have;
+    }
+    /* a stored block through the pending buffer, if worth it or flushing (:1850-1876) */
+    have = m->pending_buf_size - 5u < 65535u ? m->pending_buf_size - 5u : 65535u;
+    min_block = have < w_size ? have : w_size;
+    left = m->st_strstart - m->st_block_start;
+    if (left >= min_block || ((left || finish) && avail_in == 0 && left <= have)) {
+        len = left < have ? left : have;
+        last = finish && avail_in == 0 && len == left;
+        zo_s_stored_block(m, len, last);
+        m->st_block_start += len;
+        zo_s_flush_pending(m);
+    }
+    return last ? 2 : 0;
 }
 
 /* one deflate() call; returns ZO_OK, 1 (Z_STREAM_END) or ZO_BUF_ERROR */
@@ -1132,7 +1231,24 @@ static int zo_s_deflate(zo_stream *m, int finish)
                 return ZO_OK;
         }
     }
-    if (!m->finishing) { /* :1211-1260 */
+    if (!m->finishing && m->level == 0) { /* :1211-1260 with deflate_stored */
+        int bs = zo_s_deflate_stored(m, finish);
+        if (bs == 2 || bs == 3)
+            m->finishing = 1;
+        if (bs == 0 || bs == 2)
+            return ZO_OK;
+        if (bs == 1) { /* block_done: the flush marker; strstart = 0 as lookahead is 0 */
+            zo_put(&m->w, 0, 3);
+            zo_align(&m->w);
+            zo_byte(&m->w, 0);
+            zo_byte(&m->w, 0);
+            zo_byte(&m->w, 0xff);
+            zo_byte(&m->w, 0xff);
+            m->st_strstart = m->st_block_start = 0;
+            zo_s_flush_pending(m);
+            return ZO_OK;
+        }
+    } else if (!m->finishing) { /* :1211-1260 */
         z->n = m->given - m->run_abs;
         for (;;) {
             int ev = zo_run(z);
@@ -1245,6 +1361,7 @@ static int zo_compress_sections(uint8_t *dest, uint32_t *dest_len, const uint8_t
     m->level = level;
     m->strategy = strategy;
     m->wb = wb;
+    m->pending_buf_size = (1u << (mem_level + 6)) * 4u; /* lit_bufsize * (sizeof(U16) + 2), :362 */
 
     /* the wrapper's loop, src/zsc_compress.c:121-138 */
     uint32_t left_dest = cap_in, left_src = source_len;
@@ -1255,7 +1372,7 @@ static int zo_compress_sections(uint8_t *dest, uint32_t *dest_len, const uint8_t
             left_dest -= m->avail_out;
         }
         /* avail_in == 0: everything given so far has been read into the window */
-        if (m->run_abs + z->data_end == m->given) {
+        if (level == 0 ? m->st_read == m->given : m->run_abs + z->data_end == m->given) {
             uint32_t take = left_src < max_block_len ? left_src : max_block_len;
             m->given += take;
             left_src -= take;
@@ -1305,7 +1422,7 @@ int zo_compress(uint8_t *dest, uint32_t *dest_len, const uint8_t *source, uint32
     if (wb == 8)
         wb = 9;
 
-    if (max_block_len == 0 || level == 0) {
+    if (max_block_len == 0) {
         *unsupported = 1;
         return ZO_STREAM_ERROR;
     }
@@ -1314,7 +1431,7 @@ int zo_compress(uint8_t *dest, uint32_t *dest_len, const uint8_t *source, uint32
     err = zo_compress_max_output(source_len, max_block_len, level, window_bits, mem_level, &bound);
     if (err != ZO_OK)
         return err;
-    if (source_len > max_block_len) {
+    if (source_len > max_block_len || level == 0) { /* level 0: block sizes follow the output slices */
         *dest_len = cap_in;
         return zo_compress_sections(dest, dest_len, source, source_len, max_block_len, level, wrap, wb,
                                     mem_level, strategy, bound);

@@ -73,11 +73,12 @@ int zo_parse(const uint8_t *in, uint32_t n, int level, int window_bits_abs, int 
 
 /* whole call: semantics of reference zsc_compress_gzip2 (src/zsc_compress.c:50-160)
  * with gz_header == NULL and a work buffer of `work_len` bytes.
- * Supported: level 1..9, all five strategies, window_bits 9..15 in every wrapper, mem_level
+ * Supported: level 0..9 (0 = deflate_stored, whose block lengths follow the output slices the
+ * wrapper hands out), all five strategies, window_bits 9..15 in every wrapper, mem_level
  * 1..9, and source_len > max_block_len: the wrapper's section / output-slice loop with its
  * full-flush markers and the cases where a marker is skipped (src/zsc_compress.c:121-138,
- * src/deflate.c:1211-1264).  Level 0: ZO_STREAM_ERROR and *unsupported = 1 (so a test can
- * tell "oracle cannot" from "reference says error"). */
+ * src/deflate.c:1211-1264).  *unsupported stays 0 for every valid call now (it used to tell
+ * "oracle cannot" from "reference says error"). */
 int zo_compress(uint8_t *dest, uint32_t *dest_len, const uint8_t *source, uint32_t source_len,
                 uint32_t max_block_len, uint32_t work_len, int level, int window_bits,
                 int mem_level, int strategy, int *unsupported);

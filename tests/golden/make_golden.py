@@ -182,6 +182,16 @@ def main():
     gz_misc = {"zlib_stream_auto_detect": {"rc": rc2, "out_len": len(o2), "fields": gz_header_fields(hr, bufs)},
                "header_on_zlib_compress": R.compress(d3, 6, window_bits=15, gz_header=gz_header_for_writing()[0])[0],
                "header_on_zlib_uncompress": R.uncompress(zl, len(d3), 15, gz_header=gz_header_for_reading()[0])[0]}
+    # level 0 (deflate_stored): block lengths follow the wrapper's output slices
+    stored = []
+    for kind, size, seed in (("random", 0, 1), ("random", 1, 2), ("text", 507, 3), ("text", 32768, 4),
+                             ("random", 65531, 5), ("random", 65536, 6), ("table", 70000, 7), ("bitmap", 300000, 8)):
+        d5 = corpus.make_buffer(kind, size, seed)
+        for wb, ml, mbl, cap in ((15, 8, None, None), (31, 8, None, None), (-15, 8, None, None), (15, 1, None, None),
+                                 (12, 9, None, None), (15, 8, None, size // 2 + 7), (15, 8, 2 * size + 100, None)):
+            rc, out = R.compress(d5, 0, window_bits=wb, mem_level=ml, max_block_len=mbl, dest_cap=cap, work_len=600000)
+            stored.append({"kind": kind, "size": size, "seed": seed, "window_bits": wb, "mem_level": ml,
+                           "max_block_len": mbl, "dest_cap": cap, "rc": rc, "out_len": len(out), "out_sha256": sha(out)})
     small = []
     for cap in (0, 1, 2, 100, 12000, 40000):
         rc, out = R.compress(data, 6, dest_cap=cap)
@@ -280,7 +290,7 @@ def main():
                        "cases": cases})
     json.dump({"deflate": deflate_cases, "streams": streams, "params": params, "small": small,
                "sections": sections, "strategies": strategies,
-               "gz_header": gzh, "gz_header_misc": gz_misc}, open(os.path.join(HERE, "deflate_golden.json"), "w"), indent=0)
+               "gz_header": gzh, "gz_header_misc": gz_misc, "stored": stored}, open(os.path.join(HERE, "deflate_golden.json"), "w"), indent=0)
     json.dump({"checksums": sums, "inflate_kat": kats, "corrupt": corrupt, "resync": resync,
                "corrupt_source": {"kind": "text", "size": 20000, "seed": 3, "level": 6}},
               open(os.path.join(HERE, "inflate_golden.json"), "w"), indent=0)

@@ -75,6 +75,16 @@ def test_multi_section_golden(oracle):
             assert oracle.uncompress(out, len(data), c.get("window_bits", 15))[:2] == (0, data)
 
 
+def test_level_0_golden(oracle):
+    """level 0 = deflate_stored: stored blocks whose lengths follow the output space the wrapper
+    hands out (slices of max_block_len), src/deflate.c:1679-1880."""
+    for c in G_DEF["stored"]:
+        data = corpus.make_buffer(c["kind"], c["size"], c["seed"])
+        rc, out, uns = oracle.compress(data, 0, window_bits=c["window_bits"], mem_level=c["mem_level"],
+                                       max_block_len=c["max_block_len"], dest_cap=c["dest_cap"], work_len=600000)
+        assert not uns and (rc, len(out), sha(out)) == (c["rc"], c["out_len"], c["out_sha256"]), c
+
+
 def test_oracle_vs_reference_multi_section(oracle, reference):
     """Live fuzz against the compiled reference (container only): random section sizes, levels,
     wrappers, strategies, destination sizes."""
@@ -86,7 +96,7 @@ def test_oracle_vs_reference_multi_section(oracle, reference):
         n = rnd.choice([100, 1000, 5000, 20000, 40000, 70000, 140000]) if it % 5 else rnd.randrange(1, 3000)
         data = corpus.make_buffer(kinds[it % 8], n, it)
         mbl = rnd.choice([64, 100, 1000, 4096, 10000, 20000, 32768, 65536, 100000]) if it % 3 else 64 + rnd.randrange(1, max(2, n))
-        lvl, wb = rnd.choice([1, 2, 3, 4, 6, 9]), rnd.choice([15, 15, 31, -15, 12, -9])
+        lvl, wb = rnd.choice([0, 1, 2, 3, 4, 6, 9]), rnd.choice([15, 15, 31, -15, 12, -9])
         strat = rnd.choice([0, 0, 0, 1, 2, 3])
         cap = None if it % 4 else rnd.randrange(1, n + 200)
         a = reference.compress(data, lvl, window_bits=wb, strategy=strat, max_block_len=mbl, dest_cap=cap)
