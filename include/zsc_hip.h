@@ -45,6 +45,16 @@ ZlibReturn zsc_hip_compress_batch(U32 count, const U8 *const *sources, const U32
                                   U8 *const *dests, U32 *dest_lens, I32 *statuses, I32 level,
                                   I32 window_bits, I32 mem_level, ZlibStrategy strategy);
 
+/* Level 0 (reference deflate_stored, src/deflate.c:1679-1880): `count` buffers stored, item i
+ * like zsc_compress2(level 0, max_block_lens[i]) -- the lengths of the stored blocks follow the
+ * output slices of max_block_len the wrapper hands out, and max_block_len < source_len gives
+ * the sections their flush markers (src/zsc_compress.c:121-138). */
+ZlibReturn zsc_hip_store_batch(U32 count, const U8 *const *sources, const U32 *source_lens,
+                               const U32 *max_block_lens, U8 *const *dests, U32 *dest_lens,
+                               I32 *statuses, I32 window_bits, I32 mem_level, U32 gzip_header_len);
+/* gzip_header_len: 0, or the length of a caller-supplied gzip member header that the caller
+ * writes over the start of each stream afterwards (zsc_compress_gzip with a gz_header) */
+
 /* Decompress `count` independent streams (host memory).  source_lens[i]: in bytes
  * available, out bytes consumed (reference zsc_uncompress2, zsc_pub.h:385). */
 ZlibReturn zsc_hip_uncompress_batch(U32 count, const U8 *const *sources, U32 *source_lens,

@@ -148,12 +148,13 @@ def main():
         for f in ("name", "comment"):
             if f in kw:
                 kw[f] = kw[f].encode()
-        for lvl, strat in ((6, 0), (9, 0), (1, 0), (6, 3)):
+        for lvl, strat in ((6, 0), (9, 0), (1, 0), (6, 3), (0, 0)):
             h, keep = gz_header_for_writing(**kw)
             rc, out = R.compress(d3, lvl, window_bits=31, strategy=strat, gz_header=h)
             body = R.compress(d3, lvl, window_bits=31, strategy=strat)[1]
-            hlen = len(out) - len(body) + 10
-            assert rc == 0 and out[hlen:] == body[10:]
+            hlen = 10 + (2 + len(kw["extra"]) if "extra" in kw else 0) + (len(kw["name"]) + 1 if "name" in kw else 0) \
+                + (len(kw["comment"]) + 1 if "comment" in kw else 0) + (2 if kw.get("hcrc") else 0)
+            assert rc == 0 and (lvl == 0 or out[hlen:] == body[10:])
             case = {"spec": spec, "level": lvl, "strategy": strat, "rc": rc, "header_hex": out[:hlen].hex(),
                     "out_len": len(out), "out_sha256": sha(out), "reads": []}
             if lvl == 6 and strat == 0:

@@ -239,3 +239,36 @@ def test_window_bits_and_mem_level(z, oracle):
             if wb > 0:
                 rc, back, _, st = z.uncompress_batch(outs, [len(b) for b in bufs], window_bits=wb if wb != 8 else 15)
                 assert rc == 0 and all(x == 0 for x in st) and back == bufs
+
+
+def test_level_0_stored(z, oracle):
+    """level 0 (deflate_stored): stored blocks whose lengths follow the wrapper's output slices;
+    golden cases of the reference, then sizes / section lengths / wrappers against the oracle
+    (pinned on 1 900 such cases), multi-section streams with their flush markers included."""
+    for c in G_DEF["stored"]:
+        data = corpus.make_buffer(c["kind"], c["size"], c["seed"])
+        rc, out = z.compress2(data, max_block_len=c["max_block_len"], level=0, window_bits=c["window_bits"],
+                              mem_level=c["mem_level"], dest_len=c["dest_cap"], work_len=600000)
+        assert (rc, len(out), sha(out)) == (c["rc"], c["out_len"], c["out_sha256"]), c
+    for n in (0, 1, 507, 40000, 65531, 65536, 200000):
+        data = corpus.make_buffer("object", n, n + 5)
+        for wb, ml in ((15, 8), (31, 8), (-15, 8), (9, 1), (12, 9)):
+            for mbl in (None, 100, 4096, 65536, 3 * n + 50):
+                for cap in (None, n // 3 + 11):
+                    rc, out = z.compress2(data, max_block_len=mbl, level=0, window_bits=wb, mem_level=ml,
+                                          dest_len=cap, work_len=600000)
+                    orc, want, _ = oracle.compress(data, 0, window_bits=wb, mem_level=ml, max_block_len=mbl,
+                                                   dest_cap=cap, work_len=600000)
+                    assert (rc, out) == (orc, want), (n, wb, ml, mbl, cap)
+                    if rc == 0 and wb != 9:
+                        assert z.uncompress2(out, n, wb)[:2] == (0, data)
+    # the batch entry point stores with max_block_len = source_len
+    bufs = [corpus.make_buffer("random", n, n) for n in (0, 5, 70000, 140000)]
+    rc, outs, stats = z.compress_batch(bufs, level=0)
+    assert rc == 0
+    for b, o, s in zip(bufs, outs, stats):
+        assert (s, o) == oracle.compress(b, 0)[:2]
+    # with a caller's gzip header
+    h, keep = z.gz_header_for_writing(name=b"stored.bin", hcrc=1, time=5)
+    rc, out = z.compress2(bufs[2], level=0, window_bits=31, gz_header=h)
+    assert rc == 0 and z.uncompress2(out, len(bufs[2]), 31)[:2] == (0, bufs[2])

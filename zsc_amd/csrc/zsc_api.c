@@ -418,6 +418,29 @@ ZlibReturn zsc_compress_gzip2(U8 *dest, U32 *dest_len, const U8 *source, U32 sou
     }
     ZSC_ASSERT(max_block_len != 0);
 
+    if (lvl == 0) {
+        /* deflate_stored: the layout follows the output slices; zsc_hip_store_batch does it,
+         * sections and flush markers included */
+        const U32 hlen = gz_header != Z_NULL ? gz_header_write(gz_header, lvl, strategy, dest, 0) : 0;
+        const U8 *srcs0[1] = {source};
+        U8 *dsts0[1] = {dest};
+        U32 slen0[1] = {source_len}, mbl0[1] = {max_block_len}, dlen0[1] = {dest_cap};
+        I32 stat0[1] = {Z_STREAM_ERROR};
+        err = zsc_hip_store_batch(1, srcs0, slen0, mbl0, dsts0, dlen0, stat0, window_bits, mem_level,
+                                  hlen);
+        if (err != Z_OK) {
+            return err;
+        }
+        if (gz_header != Z_NULL) {
+            (void)gz_header_write(gz_header, lvl, strategy, dest, dlen0[0] < hlen ? dlen0[0] : hlen);
+        }
+        *dest_len = dlen0[0];
+        if (stat0[0] != Z_OK) {
+            ZSC_WARN1("In zsc_compress_gzip2(), deflate loop ended with error code %d.", stat0[0]);
+        }
+        return (ZlibReturn)stat0[0];
+    }
+
     /* what the kernels cover today; everything else fails loudly, never on a CPU path */
     if (source_len > max_block_len) {
         ZSC_WARN("In zsc_compress_gzip2(), multi-section streams (source_len > max_block_len) "

@@ -55,6 +55,76 @@ __global__ __launch_bounds__(64) void k_checksum(const uint8_t *__restrict__ in,
         res[b].adler = v;
 }
 
+/* level 0: one piece of a stored stream -- a stored block (3-bit header in its own byte,
+ * LEN, NLEN, the bytes), a flush marker, or the wrapper header / trailer; the host has laid
+ * the pieces out (StoreSim), this only moves bytes */
+typedef struct {
+    uint64_t src_off; /* first input byte of a stored block (batch input) */
+    uint64_t dst_off; /* first output byte of the piece (batch output) */
+    uint32_t len;     /* stored bytes */
+    uint32_t kind;    /* 0 stored block, 1 flush marker, 2 wrapper header, 3 trailer */
+    uint32_t arg;     /* block: BFINAL; header: CMF<<8|FLG or the gzip XFL; trailer / header: owning buffer */
+    uint32_t buf;     /* owning buffer (for the check value) */
+} ZdStorePiece;
+
+__global__ __launch_bounds__(256) void k_store(const uint8_t *__restrict__ in,
+                                               uint8_t *__restrict__ out,
+                                               const ZdStorePiece *__restrict__ pieces,
+                                               const ZdBuf *__restrict__ bufs,
+                                               const ZdResult *__restrict__ res, uint32_t npieces)
+{
+    if (blockIdx.x >= npieces)
+        return;
+    const ZdStorePiece pc = pieces[blockIdx.x];
+    uint8_t *o = out + pc.dst_off;
+    if (pc.kind == 0u) {
+        /* reference _tr_stored_block, src/trees.c:838-849 */
+        if (threadIdx.x == 0) {
+            o[0] = (uint8_t)pc.arg;
+            o[1] = (uint8_t)pc.len;
+            o[2] = (uint8_t)(pc.len >> 8);
+            o[3] = (uint8_t)~pc.len;
+            o[4] = (uint8_t)(~pc.len >> 8);
+        }
+        const uint8_t *s = in + pc.src_off;
+        for (uint32_t i = threadIdx.x; i < pc.len; i += blockDim.x)
+            o[5u + i] = s[i];
+    } else if (threadIdx.x == 0) {
+        if (pc.kind == 1u) { /* Z_FULL_FLUSH's empty stored block, src/deflate.c:1240-1243 */
+            o[0] = 0;
+            o[1] = 0;
+            o[2] = 0;
+            o[3] = 0xff;
+            o[4] = 0xff;
+        } else if (pc.kind == 2u) {
+            if (bufs[pc.buf].wrap == 1u) { /* src/deflate.c:1031-1049 */
+                o[0] = (uint8_t)(pc.arg >> 8);
+                o[1] = (uint8_t)pc.arg;
+            } else { /* :1068-1082 */
+                o[0] = 31;
+                o[1] = 139;
+                o[2] = 8;
+                o[3] = o[4] = o[5] = o[6] = o[7] = 0;
+                o[8] = (uint8_t)pc.arg;
+                o[9] = 3;
+            }
+        } else if (pc.kind == 3u) {
+            const uint32_t c = res[pc.buf].adler, n = bufs[pc.buf].in_len;
+            if (bufs[pc.buf].wrap == 1u) { /* :1282-1286 */
+                o[0] = (uint8_t)(c >> 24);
+                o[1] = (uint8_t)(c >> 16);
+                o[2] = (uint8_t)(c >> 8);
+                o[3] = (uint8_t)c;
+            } else { /* :1272-1281 */
+                for (uint32_t k = 0; k < 4; k++) {
+                    o[k] = (uint8_t)(c >> (8 * k));
+                    o[4 + k] = (uint8_t)(n >> (8 * k));
+                }
+            }
+        }
+    }
+}
+
 /* kernel 1: one workgroup (HS_WAVES wavefronts) per 32 KiB tile */
 __global__ __launch_bounds__(HS_WAVES * 64) void k_hash_sort(
     const uint8_t *__restrict__ in, const ZdBuf *__restrict__ bufs,
@@ -947,6 +1017,281 @@ extern "C" void zsc_hip_deflate_plan_destroy(zsc_hip_deflate_plan *pl)
     delete pl;
 }
 
+/* ---- level 0 --------------------------------------------------------------------- */
+
+namespace {
+
+/* Where the pieces of a level-0 stream go.  deflate_stored (reference src/deflate.c:1679-1880)
+ * sizes its stored blocks by the output space of the moment, and zsc_compress hands that
+ * space out in slices of max_block_len next to input sections of max_block_len
+ * (src/zsc_compress.c:121-138), so the layout is found by following those calls -- pure
+ * arithmetic on lengths, the bytes themselves never matter.  One StoreSim per buffer. */
+struct StoreSim {
+    uint32_t w_size = 0, pending_buf_size = 0, max_block_len = 0, source_len = 0;
+    int wrap = 1;
+    std::vector<ZdStorePiece> *pieces = nullptr;
+    uint64_t in_base = 0, out_base = 0;
+    uint32_t buf = 0, hdr_arg = 0;
+    uint32_t hdr_len = 0; /* a caller-supplied gzip member header of this length (0: the plain one) */
+    /* the stream */
+    uint32_t produced = 0, delivered = 0, avail_out = 0;
+    uint32_t given = 0, st_read = 0, st_emit = 0, st_strstart = 0, st_block_start = 0;
+    bool header_done = false, finishing = false, trailer_done = false;
+
+    void piece(uint32_t kind, uint32_t len, uint32_t arg, uint32_t bytes)
+    {
+        ZdStorePiece pc;
+        pc.src_off = in_base + st_emit;
+        pc.dst_off = out_base + produced;
+        pc.len = len;
+        pc.kind = kind;
+        pc.arg = arg;
+        pc.buf = buf;
+        pieces->push_back(pc);
+        produced += bytes;
+    }
+    void stored_block(uint32_t len, int last)
+    {
+        piece(0, len, (uint32_t)last, 5u + len);
+        st_emit += len;
+    }
+    void flush_pending()
+    {
+        const uint32_t have = produced - delivered, len = have < avail_out ? have : avail_out;
+        delivered += len;
+        avail_out -= len;
+    }
+    /* 0 need_more, 1 block_done, 2 finish_started, 3 finish_done */
+    int deflate_stored(bool finish)
+    {
+        const uint32_t window_size = 2u * w_size;
+        uint32_t min_block = std::min(pending_buf_size - 5u, w_size);
+        uint32_t avail_in = given - st_read;
+        const uint32_t used0 = avail_in;
+        uint32_t len, left, have;
+        int last = 0;
+        do {
+            len = 65535u;
+            have = 5u;
+            if (avail_out < have)
+                break;
+            have = avail_out - have;
+            left = st_strstart - st_block_start;
+            len = std::min(len, left + avail_in);
+            len = std::min(len, have);
+            if (len < min_block && ((len == 0 && !finish) || len != left + avail_in))
+                break;
+            last = finish && len == left + avail_in;
+            const uint32_t from_window = std::min(left, len);
+            stored_block(len, last);
+            st_block_start += from_window;
+            st_read += len - from_window;
+            avail_in -= len - from_window;
+            delivered += 5u + len; /* header through pending, bytes straight to next_out */
+            avail_out -= 5u + len;
+        } while (!last);
+        const uint32_t used = used0 - avail_in;
+        if (used) {
+            if (used >= w_size) {
+                st_strstart = w_size;
+            } else {
+                if (window_size - st_strstart <= used)
+                    st_strstart -= w_size;
+                st_strstart += used;
+            }
+            st_block_start = st_strstart;
+        }
+        if (last)
+            return 3;
+        if (!finish && avail_in == 0 && st_strstart == st_block_start)
+            return 1;
+        have = window_size - st_strstart - 1u;
+        if (avail_in > have && st_block_start >= w_size) {
+            st_block_start -= w_size;
+            st_strstart -= w_size;
+            have += w_size;
+        }
+        have = std::min(have, avail_in);
+        if (have) {
+            st_read += have;
+            avail_in -= have;
+            st_strstart += have;
+        }
+        have = std::min(pending_buf_size - 5u, 65535u);
+        min_block = std::min(have, w_size);
+        left = st_strstart - st_block_start;
+        if (left >= min_block || ((left || finish) && avail_in == 0 && left <= have)) {
+            len = std::min(left, have);
+            last = finish && avail_in == 0 && len == left;
+            stored_block(len, last);
+            st_block_start += len;
+            flush_pending();
+        }
+        return last ? 2 : 0;
+    }
+    /* one deflate() call: Z_OK, 1 = Z_STREAM_END, Z_BUF_ERROR (src/deflate.c:964-1295) */
+    int deflate(bool finish)
+    {
+        if (avail_out == 0)
+            return Z_BUF_ERROR;
+        if (produced != delivered) {
+            flush_pending();
+            if (avail_out == 0)
+                return Z_OK;
+        }
+        if (!header_done) {
+            header_done = true;
+            if (wrap) {
+                if (hdr_len)
+                    piece(4, 0, 0, hdr_len); /* room only: zsc_api.c writes the caller's header */
+                else
+                    piece(2, 0, hdr_arg, wrap == 1 ? 2u : 10u);
+                flush_pending();
+                if (produced != delivered)
+                    return Z_OK;
+            }
+        }
+        if (!finishing) {
+            const int bs = deflate_stored(finish);
+            if (bs == 2 || bs == 3)
+                finishing = true;
+            if (bs == 0 || bs == 2)
+                return Z_OK;
+            if (bs == 1) {
+                piece(1, 0, 0, 5u);
+                st_strstart = st_block_start = 0;
+                flush_pending();
+                return Z_OK;
+            }
+        }
+        if (!finish)
+            return Z_OK;
+        if (wrap == 0)
+            return 1;
+        if (!trailer_done) {
+            trailer_done = true;
+            piece(3, 0, 0, wrap == 1 ? 4u : 8u);
+            flush_pending();
+            return produced != delivered ? Z_OK : 1;
+        }
+        return 1;
+    }
+    /* the wrapper's loop, src/zsc_compress.c:121-138; returns the call's ZlibReturn */
+    int run(uint32_t dest_cap)
+    {
+        uint32_t left_dest = dest_cap, left_src = source_len;
+        int err = Z_OK;
+        while (err == Z_OK) {
+            if (avail_out == 0) {
+                avail_out = std::min(left_dest, max_block_len);
+                left_dest -= avail_out;
+            }
+            if (st_read == given) {
+                const uint32_t take = std::min(left_src, max_block_len);
+                given += take;
+                left_src -= take;
+            }
+            err = deflate(left_src == 0);
+        }
+        return err == 1 ? Z_OK : err;
+    }
+};
+
+} // namespace
+
+extern "C" ZlibReturn zsc_hip_store_batch(U32 count, const U8 *const *sources, const U32 *source_lens,
+                                          const U32 *max_block_lens, U8 *const *dests,
+                                          U32 *dest_lens, I32 *statuses, I32 window_bits,
+                                          I32 mem_level, U32 gzip_header_len)
+{
+    ZSC_ASSERT(sources != Z_NULL);
+    ZSC_ASSERT(source_lens != Z_NULL);
+    ZSC_ASSERT(max_block_lens != Z_NULL);
+    ZSC_ASSERT(dests != Z_NULL);
+    ZSC_ASSERT(dest_lens != Z_NULL);
+    if (count == 0)
+        return Z_OK;
+    if (zsc_hip_init(-1) != Z_OK)
+        return Z_STREAM_ERROR;
+    int wrap = 1, wbits = 15;
+    if (!offloadable(1, window_bits, mem_level, Z_DEFAULT_STRATEGY, &wrap, &wbits))
+        return Z_STREAM_ERROR;
+    /* zlib header of level 0: level_flags 0 (src/deflate.c:1031-1049); gzip XFL 4 (:1075-1078) */
+    uint32_t zh = (8u + (((uint32_t)wbits - 8u) << 4)) << 8;
+    zh += 31u - zh % 31u;
+    std::vector<ZdStorePiece> pieces;
+    std::vector<ZdBuf> bufs(count);
+    std::vector<uint32_t> give(count), stat(count);
+    uint64_t in_bytes = 0, out_bytes = 0;
+    for (U32 i = 0; i < count; i++) {
+        ZSC_ASSERT(max_block_lens[i] != 0);
+        StoreSim sim;
+        sim.w_size = 1u << wbits;
+        sim.pending_buf_size = (1u << (mem_level + 6)) * 4u; /* lit_bufsize * 4, src/deflate.c:362 */
+        sim.max_block_len = max_block_lens[i];
+        sim.source_len = source_lens[i];
+        sim.wrap = wrap;
+        sim.pieces = &pieces;
+        sim.in_base = in_bytes;
+        sim.out_base = out_bytes;
+        sim.buf = i;
+        sim.hdr_arg = wrap == 1 ? zh : 4u;
+        sim.hdr_len = wrap == 2 ? gzip_header_len : 0u;
+        stat[i] = (uint32_t)sim.run(dest_lens[i]);
+        give[i] = sim.delivered;
+        memset(&bufs[i], 0, sizeof(ZdBuf));
+        bufs[i].in_off = in_bytes;
+        bufs[i].out_off = out_bytes;
+        bufs[i].in_len = source_lens[i];
+        bufs[i].wrap = (uint32_t)wrap;
+        in_bytes += ((uint64_t)source_lens[i] + 15u) & ~15ull;
+        out_bytes += ((uint64_t)sim.produced + 15u) & ~15ull;
+    }
+    DevBuf d_in, d_out, d_pieces, d_bufs, d_res;
+    ZlibReturn rc = Z_OK;
+    if (!d_in.ensure(in_bytes + 64) || !d_out.ensure(out_bytes + 64) ||
+        !d_pieces.ensure(sizeof(ZdStorePiece) * std::max<size_t>(1, pieces.size())) ||
+        !d_bufs.ensure(sizeof(ZdBuf) * count) || !d_res.ensure(sizeof(ZdResult) * count))
+        rc = Z_MEM_ERROR;
+    for (U32 i = 0; i < count && rc == Z_OK; i++) {
+        ZSC_ASSERT(sources[i] != Z_NULL);
+        if (source_lens[i] && hipMemcpy((uint8_t *)d_in.p + bufs[i].in_off, sources[i], source_lens[i],
+                                        hipMemcpyHostToDevice) != hipSuccess)
+            rc = Z_STREAM_ERROR;
+    }
+    if (rc == Z_OK &&
+        (hipMemcpy(d_bufs.p, bufs.data(), sizeof(ZdBuf) * count, hipMemcpyHostToDevice) != hipSuccess ||
+         (!pieces.empty() && hipMemcpy(d_pieces.p, pieces.data(), sizeof(ZdStorePiece) * pieces.size(),
+                                       hipMemcpyHostToDevice) != hipSuccess)))
+        rc = Z_STREAM_ERROR;
+    if (rc == Z_OK) {
+        hipLaunchKernelGGL(k_checksum, dim3(count), dim3(64), 0, nullptr, (const uint8_t *)d_in.p,
+                           (const ZdBuf *)d_bufs.p, (ZdResult *)d_res.p, count);
+        if (!pieces.empty())
+            hipLaunchKernelGGL(k_store, dim3((uint32_t)pieces.size()), dim3(256), 0, nullptr,
+                               (const uint8_t *)d_in.p, (uint8_t *)d_out.p,
+                               (const ZdStorePiece *)d_pieces.p, (const ZdBuf *)d_bufs.p,
+                               (const ZdResult *)d_res.p, (uint32_t)pieces.size());
+        if (hipDeviceSynchronize() != hipSuccess || hipGetLastError() != hipSuccess)
+            rc = Z_STREAM_ERROR;
+    }
+    for (U32 i = 0; i < count && rc == Z_OK; i++) {
+        ZSC_ASSERT(dests[i] != Z_NULL);
+        if (give[i] && hipMemcpy(dests[i], (uint8_t *)d_out.p + bufs[i].out_off, give[i],
+                                 hipMemcpyDeviceToHost) != hipSuccess)
+            rc = Z_STREAM_ERROR;
+        dest_lens[i] = give[i];
+        if (statuses)
+            statuses[i] = (I32)stat[i];
+    }
+    d_in.release();
+    d_out.release();
+    d_pieces.release();
+    d_bufs.release();
+    d_res.release();
+    return rc;
+}
+
 /* host-pointer batch: stage through one pair of device buffers */
 extern "C" ZlibReturn zsc_hip_compress_batch(U32 count, const U8 *const *sources,
                                              const U32 *source_lens, U8 *const *dests,
@@ -960,6 +1305,14 @@ extern "C" ZlibReturn zsc_hip_compress_batch(U32 count, const U8 *const *sources
     ZSC_ASSERT(dest_lens != Z_NULL);
     if (count == 0)
         return Z_OK;
+    if (level == Z_NO_COMPRESSION) {
+        /* level 0: stored blocks; max_block_len = source_len, the smallest a single section allows */
+        std::vector<U32> mbl(count);
+        for (U32 i = 0; i < count; i++)
+            mbl[i] = source_lens[i] ? source_lens[i] : 1u;
+        return zsc_hip_store_batch(count, sources, source_lens, mbl.data(), dests, dest_lens, statuses,
+                                   window_bits, mem_level, 0);
+    }
     std::vector<uint64_t> in_off(count), out_off(count);
     std::vector<U32> caps(count), lens(count);
     std::vector<I32> stat(count);
