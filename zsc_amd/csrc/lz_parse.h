@@ -205,8 +205,8 @@ DEV uint32_t lz_lcp(const L *lds, const LzState &st, uint32_t q, uint32_t p, uin
     LANEVAR(int, differs);
     FOR_LANES
     {
-        uint32_t a = ld_u32(&lds->ring[lz_ridx<L>(st, q + 4u * (uint32_t)LANE)]);
-        uint32_t b = ld_u32(&lds->ring[lz_ridx<L>(st, p + 4u * (uint32_t)LANE)]);
+        uint32_t a = lds_u32(lds->ring, lz_ridx<L>(st, q + 4u * (uint32_t)LANE));
+        uint32_t b = lds_u32(lds->ring, lz_ridx<L>(st, p + 4u * (uint32_t)LANE));
         LV(diff) = a ^ b;
         LV(differs) = LV(diff) != 0;
     }
@@ -272,7 +272,7 @@ DEV void lz_ensure_ranks(const LzJob &job, L *lds, LzState &st, uint32_t p)
     do {                                                                                      \
         (blocked) = 0;                                                                        \
         const uint32_t _hs = (job.cfg.hbits + 2u) / 3u, _hm = (1u << job.cfg.hbits) - 1u;     \
-        const uint32_t _wp = UNI(ld_u32(&lds->ring[lz_ridx<L>(st, (P))]));                    \
+        const uint32_t _wp = UNI(lds_u32(lds->ring, lz_ridx<L>(st, (P))));                    \
         const uint32_t _hp = (((_wp & 0xffu) << (2u * _hs)) ^ (((_wp >> 8) & 0xffu) << _hs) ^ \
                               ((_wp >> 16) & 0xffu)) & _hm;                                   \
         for (uint32_t _x0 = (Q) + 1u; _x0 < (P) && !(blocked); _x0 += WAVE) {                 \
@@ -282,7 +282,7 @@ DEV void lz_ensure_ranks(const LzJob &job, L *lds, LzState &st, uint32_t p)
                 const uint32_t _x = _x0 + (uint32_t)LANE;                                     \
                 int _s = 0;                                                                   \
                 if (_x < (P)) {                                                               \
-                    const uint32_t _w = ld_u32(&lds->ring[lz_ridx<L>(st, _x)]);               \
+                    const uint32_t _w = lds_u32(lds->ring, lz_ridx<L>(st, _x));               \
                     const uint32_t _h = (((_w & 0xffu) << (2u * _hs)) ^                       \
                                          (((_w >> 8) & 0xffu) << _hs) ^ ((_w >> 16) & 0xffu)) & _hm; \
                     _s = _h == _hp && MEMB(_x);                                               \
@@ -375,15 +375,15 @@ typedef struct {
                 (verdict) = 2;                                                                \
                 break;                                                                        \
             }                                                                                 \
-            sc.sb = UNI(ld_u16(&lds->ring[lz_ridx<L>(st, sc.p + sc.best - 1)]));              \
+            sc.sb = UNI((lds_u32(lds->ring, lz_ridx<L>(st, sc.p + sc.best - 1)) & 0xffffu));              \
         }                                                                                     \
         const int _ends = ((_m_hash & ~_m_reach) | (_m_in & ~_m_alive)) != 0; /* chain leaves the window */         \
         FOR_LANES                                                                             \
         {                                                                                     \
             int _c = 0;                                                                       \
             if (LV(_alive)) {                                                                 \
-                _c = ld_u16(&lds->ring[lz_ridx<L>(st, LV(_q))]) == sc.s01 &&                  \
-                     ld_u16(&lds->ring[lz_ridx<L>(st, LV(_q) + sc.best - 1)]) == sc.sb;       \
+                _c = (lds_u32(lds->ring, lz_ridx<L>(st, LV(_q))) & 0xffffu) == sc.s01 &&                  \
+                     (lds_u32(lds->ring, lz_ridx<L>(st, LV(_q) + sc.best - 1)) & 0xffffu) == sc.sb;       \
             }                                                                                 \
             LV(_pass) = _c;                                                                   \
         }                                                                                     \
@@ -400,13 +400,13 @@ typedef struct {
                     (verdict) = 2;                                                            \
                     break;                                                                    \
                 }                                                                             \
-                sc.sb = UNI(ld_u16(&lds->ring[lz_ridx<L>(st, sc.p + sc.best - 1)]));          \
+                sc.sb = UNI((lds_u32(lds->ring, lz_ridx<L>(st, sc.p + sc.best - 1)) & 0xffffu));          \
                 FOR_LANES                                                                     \
                 {                                                                             \
                     int _c = 0;                                                               \
                     if (LV(_alive) && LANE > _j) {                                            \
-                        _c = ld_u16(&lds->ring[lz_ridx<L>(st, LV(_q))]) == sc.s01 &&          \
-                             ld_u16(&lds->ring[lz_ridx<L>(st, LV(_q) + sc.best - 1)]) == sc.sb; \
+                        _c = (lds_u32(lds->ring, lz_ridx<L>(st, LV(_q))) & 0xffffu) == sc.s01 &&          \
+                             (lds_u32(lds->ring, lz_ridx<L>(st, LV(_q) + sc.best - 1)) & 0xffffu) == sc.sb; \
                     }                                                                         \
                     LV(_pass) = _c;                                                           \
                 }                                                                             \
@@ -526,7 +526,7 @@ DEV void lz_parse_lazy(const LzJob &job, L *lds)
         if (searching) {
             LzSearch sc;
             sc.p = p;
-            const uint32_t w0 = UNI(ld_u32(&lds->ring[lz_ridx<L>(st, p)]));
+            const uint32_t w0 = UNI(lds_u32(lds->ring, lz_ridx<L>(st, p)));
             sc.h = (((w0 & 0xff) << 10) ^ (((w0 >> 8) & 0xff) << 5) ^ ((w0 >> 16) & 0xff)) & ZD_HASH_MASK;
             sc.s01 = w0 & 0xffff;
             sc.sb = 0;
@@ -629,7 +629,7 @@ DEV void lz_parse_greedy(const LzJob &job, LzLdsFast *lds)
             lz_mark_inserted<L>(lds, st, p);
             LzSearch sc;
             sc.p = p;
-            const uint32_t w0 = UNI(ld_u32(&lds->ring[lz_ridx<L>(st, p)]));
+            const uint32_t w0 = UNI(lds_u32(lds->ring, lz_ridx<L>(st, p)));
             sc.h = (((w0 & 0xff) << 10) ^ (((w0 >> 8) & 0xff) << 5) ^ ((w0 >> 16) & 0xff)) & ZD_HASH_MASK;
             sc.s01 = w0 & 0xffff;
             sc.sb = 0;

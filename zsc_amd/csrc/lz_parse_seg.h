@@ -183,7 +183,7 @@ DEV void sg_phase_begin(const LzJob &job, SgLds *lds, int w)
             const uint32_t _lo = READLANE(pw, _k >> 2), _hi = READLANE(pw, (_k >> 2) + 1u);   \
             (out) = (uint32_t)((((uint64_t)_hi << 32) | _lo) >> ((_k & 3u) * 8u));            \
         } else {                                                                              \
-            (out) = UNI(ld_u32(&lds->ring[lz_ridx<L>(st, (pos))]));                           \
+            (out) = UNI(lds_u32(lds->ring, lz_ridx<L>(st, (pos))));                           \
         }                                                                                     \
     } while (0)
 
@@ -204,13 +204,13 @@ DEV void sg_phase_begin(const LzJob &job, SgLds *lds, int w)
         SG_COUNT(1, 1);                                                                       \
         if (pv_at != p) {                                                                     \
             pv_at = p;                                                                        \
-            FOR_LANES { LV(pv) = ld_u32(&lds->ring[lz_ridx<L>(st, p + 4u * (uint32_t)LANE)]); } \
+            FOR_LANES { LV(pv) = lds_u32(lds->ring, lz_ridx<L>(st, p + 4u * (uint32_t)LANE)); } \
         }                                                                                     \
         LANEVAR(uint32_t, _diff);                                                             \
         LANEVAR(int, _differs);                                                               \
         FOR_LANES                                                                             \
         {                                                                                     \
-            LV(_diff) = ld_u32(&lds->ring[lz_ridx<L>(st, (QJ) + 4u * (uint32_t)LANE)]) ^ LV(pv); \
+            LV(_diff) = lds_u32(lds->ring, lz_ridx<L>(st, (QJ) + 4u * (uint32_t)LANE)) ^ LV(pv); \
             LV(_differs) = LV(_diff) != 0;                                                    \
         }                                                                                     \
         const uint64_t _dm = BALLOT(_differs);                                                \
@@ -279,8 +279,8 @@ DEV void sg_phase_begin(const LzJob &job, SgLds *lds, int w)
             const int live = LV(_alive);                                                      \
             const uint32_t r0 = live ? lz_ridx<L>(st, LV(_q)) : 0u;                           \
             const uint32_t r1 = live ? lz_ridx<L>(st, LV(_q) + best - 1) : 0u;                \
-            const uint32_t w0 = ld_u32(&lds->ring[r0]);                                       \
-            const uint32_t g1 = ld_u16(&lds->ring[r1]);                                       \
+            const uint32_t w0 = lds_u32(lds->ring, r0);                                       \
+            const uint32_t g1 = lds_u32(lds->ring, r1) & 0xffffu;                             \
             LV(_w0) = w0;                                                                     \
             LV(_pass) = live && g1 == sb && (w0 & 0xffffu) == (s0123 & 0xffffu);              \
             LV(_maybe) = live && w0 == s0123;                                                 \
@@ -327,7 +327,7 @@ DEV void sg_phase_begin(const LzJob &job, SgLds *lds, int w)
                     const int live = LV(_alive) && LANE > _j &&                               \
                                      (LV(_w0) & 0xffffu) == (s0123 & 0xffffu);                \
                     const uint32_t r1 = live ? lz_ridx<L>(st, LV(_q) + best - 1) : 0u;        \
-                    LV(_pass) = live && ld_u16(&lds->ring[r1]) == sb;                         \
+                    LV(_pass) = live && (lds_u32(lds->ring, r1) & 0xffffu) == sb;            \
                 }                                                                             \
                 _todo = BALLOT(_pass);                                                        \
             } else {                                                                          \
@@ -403,7 +403,7 @@ DEV void sg_phase_begin(const LzJob &job, SgLds *lds, int w)
                     const int _j = 31 - CLZ32(_mm);                                           \
                     _mm &= ~(1u << _j);                                                       \
                     const uint32_t _qj = _R0 + 16u * (uint32_t)_l + (uint32_t)_j - _off;      \
-                    const uint32_t _t = UNI(ld_u32(&lds->ring[lz_ridx<L>(st, _qj)]));         \
+                    const uint32_t _t = UNI(lds_u32(lds->ring, lz_ridx<L>(st, _qj)));         \
                     if (((_t ^ s0123) & 0xffffffu) != 0)                                      \
                         continue; /* not on p's chain, or fails :1466-1467 */                 \
                     uint32_t _len = 3;                                                        \
@@ -545,7 +545,7 @@ DEV void sg_parse_segment(const LzJob &job, SgLds *lds, const SgScratch &scr, ui
             pw_at = p & ~3u;
             if (pw_at >= 4u)
                 pw_at -= 4u;
-            FOR_LANES { LV(pw) = ld_u32(&lds->ring[lz_ridx<L>(st, pw_at + 4u * (uint32_t)LANE)]); }
+            FOR_LANES { LV(pw) = lds_u32(lds->ring, lz_ridx<L>(st, pw_at + 4u * (uint32_t)LANE)); }
         }
 
         uint32_t s0123;

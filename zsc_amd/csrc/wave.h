@@ -92,6 +92,11 @@ static inline uint32_t ld_u16(const uint8_t *p)
     memcpy(&v, p, 2);
     return v;
 }
+/* an unaligned 32-bit read from LDS: same as ld_u32 here */
+static inline uint32_t lds_u32(const uint8_t *base, uint32_t idx)
+{
+    return ld_u32(base + idx);
+}
 #define LDS_ADD_U32(ptr, v) (*(ptr) += (v))
 #define LDS_FETCH_ADD_U32(ptr, v) ((*(ptr) += (v)) - (v)) /* returns the old value */
 #define LDS_OR_U32(ptr, v) (*(ptr) |= (v))
@@ -178,6 +183,15 @@ DEV uint32_t ld_u16(const uint8_t *p)
     uint16_t v;
     __builtin_memcpy(&v, p, 2);
     return v;
+}
+/* An unaligned 32-bit read from LDS as two aligned dwords and a funnel shift.  gfx950 does
+ * execute an unaligned ds_read_b32, but at ~47 LDS cycles a wave instead of a handful
+ * (SQ_LDS_UNALIGNED_STALL: 153 of 207 CU cycles per input byte in the parser before this).
+ * `base` must be 4-byte aligned and 4 readable bytes must follow base[idx + 3]. */
+DEV uint32_t lds_u32(const uint8_t *base, uint32_t idx)
+{
+    const uint32_t *w = (const uint32_t *)(base + (idx & ~3u));
+    return __builtin_amdgcn_alignbyte(w[1], w[0], idx & 3u);
 }
 #define LDS_ADD_U32(ptr, v) atomicAdd((ptr), (v))
 #define LDS_FETCH_ADD_U32(ptr, v) atomicAdd((ptr), (v))
