@@ -175,17 +175,8 @@ DEV void sg_phase_begin(const LzJob &job, SgLds *lds, int w)
  * but cannot improve on best_len only cost chain budget, which is settled for all of
  * them at once with a popcount. */
 
-/* two consecutive dwords of the 256-byte register copy of the window at pw_at */
-#define SG_PEEK32(pos, out)                                                                   \
-    do {                                                                                      \
-        const uint32_t _k = (pos)-pw_at;                                                      \
-        if (_k <= 248u) {                                                                     \
-            const uint32_t _lo = READLANE(pw, _k >> 2), _hi = READLANE(pw, (_k >> 2) + 1u);   \
-            (out) = (uint32_t)((((uint64_t)_hi << 32) | _lo) >> ((_k & 3u) * 8u));            \
-        } else {                                                                              \
-            (out) = UNI(lds_u32(lds->ring, lz_ridx<L>(st, (pos))));                           \
-        }                                                                                     \
-    } while (0)
+/* four bytes of the window as a wave-uniform value */
+#define SG_PEEK32(pos, out) ((out) = UNI(lds_u32(lds->ring, lz_ridx<L>(st, (pos)))))
 
 /* entries of candidates 64*B .. 64*B+63; lanes past the end of the chain read entry 0 of
  * the tile (a valid address) and are masked later -- cheaper than predicating the load */
@@ -478,13 +469,12 @@ DEV void sg_parse_segment(const LzJob &job, SgLds *lds, const SgScratch &scr, ui
      *   stg      tokens not yet written out;  sdx  token counts at fresh positions */
     LANEVAR(uint32_t, mrk);
     LANEVAR(uint32_t, mcn);
-    LANEVAR(uint32_t, pw);
     LANEVAR(uint32_t, pv);
     LANEVAR(uint32_t, stg);
     LANEVAR(uint32_t, sdx);
-    FOR_LANES { LV(mrk) = LV(mcn) = LV(pw) = LV(pv) = LV(stg) = LV(sdx) = 0; }
+    FOR_LANES { LV(mrk) = LV(mcn) = LV(pv) = LV(stg) = LV(sdx) = 0; }
     /* the two caches start out of range of p, so that their one range test fails */
-    uint32_t mt_at = p + 4096u, pw_at = p + 4096u, pv_at = 0xffffffffu;
+    uint32_t mt_at = p + 4096u, pv_at = 0xffffffffu;
     uint32_t lit = 0;                      /* the byte at p-1 */
     if (pending)
         lit = UNI(lds->ring[lz_ridx<L>(st, p - 1u)]);
@@ -541,12 +531,6 @@ DEV void sg_parse_segment(const LzJob &job, SgLds *lds, const SgScratch &scr, ui
                     LV(sdx) = ntok;
             }
         }
-        if (p - 1u - pw_at > 223u) { /* p-1 .. p+24 must lie inside the copy */
-            pw_at = p & ~3u;
-            if (pw_at >= 4u)
-                pw_at -= 4u;
-            FOR_LANES { LV(pw) = lds_u32(lds->ring, lz_ridx<L>(st, pw_at + 4u * (uint32_t)LANE)); }
-        }
 
         uint32_t s0123;
         SG_PEEK32(p, s0123);
@@ -584,9 +568,11 @@ DEV void sg_parse_segment(const LzJob &job, SgLds *lds, const SgScratch &scr, ui
                 LANEVAR(uint32_t, f2);
                 LANEVAR(uint32_t, f3);
                 SG_LOAD(e0, 0u);
-                SG_LOAD(e1, 1u);
-                SG_LOAD(e2, 2u);
-                SG_LOAD(e3, 3u);
+                if (total > 64u) { /* most chains of text fit one load */
+                    SG_LOAD(e1, 1u);
+                    SG_LOAD(e2, 2u);
+                    SG_LOAD(e3, 3u);
+                }
                 /* the chain head may lie at exactly MAX_DIST (:2032), later links may not */
                 const uint32_t ent0 = READLANE(e0, 0);
                 const uint32_t q0 = tileA + (ent0 & ZD_TILE_MASK) - (nA ? 0u : ZD_TILE);
@@ -604,8 +590,12 @@ DEV void sg_parse_segment(const LzJob &job, SgLds *lds, const SgScratch &scr, ui
                         fin = 1;
                 }
                 if (!fin) {
-                    SG_PEEK32(p + best - 1, sb);
-                    sb &= 0xffffu;
+                    if (best <= 3u) /* the two bytes are among the four read at p */
+                        sb = (s0123 >> (8u * (best - 1u))) & 0xffffu;
+                    else {
+                        SG_PEEK32(p + best - 1, sb);
+                        sb &= 0xffffu;
+                    }
                 }
                 int sweep = 0;
                 if (total > 256u) {
