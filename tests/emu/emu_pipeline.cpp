@@ -18,11 +18,11 @@ struct uint4 { uint32_t x, y, z, w; };
 #include "../../zsc_amd/csrc/lz_parse.h"
 /* event counters for tools/seg_stats.py: [0] batches, [1] long compares; per segment a
  * record (segment | redo flag, batches) is appended to g_sg_log */
-extern "C" { unsigned long long g_sg_cnt[4]; unsigned g_sg_log[1 << 20]; unsigned g_sg_nlog; }
+extern "C" { unsigned long long g_sg_cnt[8]; unsigned g_sg_log[1 << 20]; unsigned g_sg_nlog; }
 static unsigned long long g_sg_mark;
 static inline void sg_count(int what, unsigned n)
 {
-    if (what < 2)
+    if (what < 2 || what >= 4)
         g_sg_cnt[what] += n;
     else if (what == 2) {
         g_sg_mark = g_sg_cnt[0];

@@ -279,6 +279,7 @@ DEV void sg_phase_begin(const LzJob &job, SgLds *lds, int w)
         uint64_t _todo = BALLOT(_pass);                                                       \
         const uint64_t _m_maybe = cap > 3u ? BALLOT(_maybe) : 0ull;                           \
         while (_todo != 0) {                                                                  \
+            SG_COUNT(6, 1);                                                                   \
             /* passers that can beat best_len: any at all while best_len is 2, later only     \
              * those whose first four bytes match */                                          \
             const uint64_t _cand = best >= 3u ? (_todo & _m_maybe) : _todo;                   \
@@ -491,6 +492,7 @@ DEV void sg_parse_segment(const LzJob &job, SgLds *lds, const SgScratch &scr, ui
                 break;
             }
         }
+        SG_COUNT(4, 1);
         const int fresh = ((uint32_t)pending | (cur_len ^ 2u)) == 0;
         if (p >= e_s) {
             if (p >= E) {
@@ -550,6 +552,7 @@ DEV void sg_parse_segment(const LzJob &job, SgLds *lds, const SgScratch &scr, ui
             const uint32_t rh = READLANE(mrk, p - mt_at), cn = READLANE(mcn, p - mt_at);
             const uint32_t nA = cn & 0xffffu, total = nA + (cn >> 16);
             if (total != 0) {
+                SG_COUNT(5, 1);
                 const int32_t hiA = (int32_t)(rh & 0xffffu) - 1, hiB = (int32_t)(rh >> 16);
                 const uint32_t tileA = p & ~ZD_TILE_MASK;
                 const uint32_t *runA = job.sorted + (uint64_t)(p >> 15) * ZD_TILE;
