@@ -55,6 +55,18 @@ ZlibReturn zsc_hip_store_batch(U32 count, const U8 *const *sources, const U32 *s
 /* gzip_header_len: 0, or the length of a caller-supplied gzip member header that the caller
  * writes over the start of each stream afterwards (zsc_compress_gzip with a gz_header) */
 
+/* Levels 1-9 with source_lens[i] > max_block_lens[i]: item i like zsc_compress2(max_block_lens[i])
+ * (reference src/zsc_compress.c:121-138) -- the input goes to deflate() in sections of
+ * max_block_len with Z_FULL_FLUSH, the output in slices of max_block_len.  All sections of all
+ * items are parsed at once; where an output slice ran out at a place that lets the next section
+ * in early (SURVEY finding 2) the run is parsed again with the history (zsc_amd/csrc/sections.h).
+ * gzip_header_len as in zsc_hip_store_batch. */
+ZlibReturn zsc_hip_compress_sections_batch(U32 count, const U8 *const *sources,
+                                           const U32 *source_lens, const U32 *max_block_lens,
+                                           U8 *const *dests, U32 *dest_lens, I32 *statuses,
+                                           I32 level, I32 window_bits, I32 mem_level,
+                                           ZlibStrategy strategy, U32 gzip_header_len);
+
 /* Decompress `count` independent streams (host memory).  source_lens[i]: in bytes
  * available, out bytes consumed (reference zsc_uncompress2, zsc_pub.h:385). */
 ZlibReturn zsc_hip_uncompress_batch(U32 count, const U8 *const *sources, U32 *source_lens,

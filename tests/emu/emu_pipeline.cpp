@@ -40,6 +40,7 @@ static inline void sg_count(int what, unsigned n)
 #include "../../zsc_amd/csrc/bit_emit.h"
 #include "../../zsc_amd/csrc/checksum.h"
 #include "../../zsc_amd/csrc/inflate.h"
+#include "../../zsc_amd/csrc/sections.h"
 
 static const ZdLevel kLevels[10] = {
     {0, 0, 0, 0, 0},       {4, 4, 8, 4, 0},       {4, 5, 16, 8, 0},     {4, 6, 32, 32, 0},
@@ -151,14 +152,16 @@ static void run_parse(const LzJob &job)
     if (job.strategy == 2u || job.strategy == 3u) { /* Z_HUFFMAN_ONLY, Z_RLE */
         SpLds *lds = (SpLds *)malloc(sizeof(SpLds));
         memset(lds, 0x5D, sizeof(SpLds));
-        if (job.strategy == 2u)
+        if (job.nsched)
+            lz_parse_simple_joints(job, lds);
+        else if (job.strategy == 2u)
             lz_parse_huff(job, lds);
         else
             lz_parse_rle(job, lds);
         free(lds);
         return;
     }
-    if (job.cfg.slow && (g_seg_mode >= 2 || (g_seg_mode == 0 && job.n > 18432u))) {
+    if (job.cfg.slow && job.nsched == 0 && (g_seg_mode >= 2 || (g_seg_mode == 0 && job.n > 18432u))) {
         run_parse_seg(job, g_seg_mode == 3 ? 3 : 2);
         return;
     }
@@ -224,6 +227,10 @@ extern "C" int emu_parse(const uint8_t *src, uint32_t n, int level, int strategy
     job.out = &out;
     job.cfg = level_cfg(level);
     job.strategy = (uint32_t)strategy;
+    job.more = 0;
+    job.sched = nullptr;
+    job.nsched = 0;
+    job.n0 = n;
     run_parse(job);
     *nsyms = out.nsyms;
     *nblocks = out.nblocks;
@@ -270,6 +277,10 @@ extern "C" int emu_compress(const uint8_t *src, uint32_t n, int level, int wrap,
     job.out = &po;
     job.cfg = level_cfg(level);
     job.strategy = (uint32_t)strategy;
+    job.more = 0;
+    job.sched = nullptr;
+    job.nsched = 0;
+    job.n0 = n;
     run_parse(job);
 
     ZdBuf buf;
@@ -320,4 +331,154 @@ extern "C" int emu_uncompress(const uint8_t *src, uint32_t n, int window_bits, u
     *consumed = res.consumed;
     memcpy(dst, out.data(), res.out_len <= cap ? res.out_len : cap);
     return res.status;
+}
+
+
+/* ---- zsc_compress with source_len > max_block_len (sections.h), kernel by kernel ---- */
+
+struct EmuSecRunner {
+    const uint8_t *src;
+    int level, strategy;
+    std::vector<std::vector<std::vector<uint32_t>>> outs; /* [round][job] */
+    uint32_t parses = 0;
+
+    int operator()(std::vector<SecRun *> &jobs, uint32_t round)
+    {
+        outs.resize(round + 1);
+        outs[round].resize(jobs.size());
+        for (size_t j = 0; j < jobs.size(); j++) {
+            SecRun &r = *jobs[j];
+            parses++;
+            EmuChains c;
+            build_chains(c, src + r.start, r.n);
+            std::vector<uint32_t> syms((size_t)r.n + 64);
+            const uint32_t max_blocks = r.n / ((1u << (g_mem_level + 6)) - 1u) + 2 + (uint32_t)r.sched.size();
+            std::vector<ZdBlockRec> recs(max_blocks);
+            std::vector<ZdBlockPlan> plans(max_blocks);
+            ZdParseOut po = {0, 0};
+            LzJob job;
+            job.in = c.in.data();
+            job.n = r.n;
+            job.sorted = c.sorted.data();
+            job.rank = c.rank.data();
+            job.hib = c.hib.data();
+            job.cnt = c.cnt.data();
+            job.syms = syms.data();
+            job.blocks = recs.data();
+            job.out = &po;
+            job.cfg = level_cfg(level);
+            job.strategy = (uint32_t)strategy;
+            job.more = r.more ? 1u : 0u;
+            job.sched = r.sched.data();
+            job.nsched = (uint32_t)r.sched.size();
+            job.n0 = r.n0;
+            run_parse(job);
+            if (po.nblocks > max_blocks)
+                return -2;
+
+            ZdBuf buf;
+            memset(&buf, 0, sizeof buf);
+            buf.in_len = r.n;
+            buf.max_blocks = max_blocks;
+            buf.out_cap = r.n + (r.n >> 3) + 1024u;
+            buf.level = (uint32_t)level;
+            buf.wrap = 0;
+            buf.strategy = (uint32_t)strategy;
+            buf.wbits = (uint32_t)g_wbits;
+            buf.more = job.more;
+            ZdResult res;
+            memset(&res, 0, sizeof res);
+            for (uint32_t b = 0; b < po.nblocks; b++) {
+                HpLds hl;
+                memset(&hl, 0x5A, sizeof hl);
+                huff_plan_block(syms.data() + recs[b].sym_begin, &recs[b], (uint32_t)strategy, &plans[b], &hl);
+            }
+            std::vector<uint32_t> &outw = outs[round][j];
+            outw.assign(((size_t)buf.out_cap + 64) / 4 + 4, 0xCDCDCDCD);
+            layout_buffer(&buf, &po, recs.data(), plans.data(), &res, (uint8_t *)outw.data());
+            if (res.status != 0)
+                return res.status;
+            for (uint32_t b = 0; b < po.nblocks; b++) {
+                BeLds bl;
+                memset(&bl, 0x77, sizeof bl);
+                emit_block(c.in.data(), syms.data() + recs[b].sym_begin, &recs[b], &plans[b], outw.data(), &bl);
+            }
+            r.blocks.clear();
+            for (uint32_t b = 0; b < po.nblocks; b++) {
+                SecBlock sb;
+                sb.upto = recs[b].in_begin + recs[b].in_len;
+                sb.end_bit = b + 1 < po.nblocks ? plans[b + 1].bit_off : res.bits;
+                sb.data_end = recs[b].data_end;
+                sb.cut = recs[b].cut;
+                sb.last = recs[b].last;
+                r.blocks.push_back(sb);
+            }
+            r.round = round;
+            r.job = (uint32_t)j;
+        }
+        return 0;
+    }
+};
+
+/* returns the call's ZlibReturn; *rounds_out / *parses_out tell how much work it took */
+extern "C" int emu_compress_sections(const uint8_t *src, uint32_t n, uint32_t max_block_len, int level,
+                                     int wrap, int strategy, uint8_t *out, uint32_t dest_cap,
+                                     uint32_t *out_len, uint32_t *parses_out)
+{
+    std::vector<SecStream> streams(1);
+    SecStream &s = streams[0];
+    s.source_len = n;
+    s.max_block_len = max_block_len;
+    s.dest_cap = dest_cap;
+    s.wrap = wrap;
+    s.hdr_len = wrap == 1 ? 2u : wrap == 2 ? 10u : 0u;
+    EmuSecRunner runner;
+    runner.src = src;
+    runner.level = level;
+    runner.strategy = strategy;
+    const int rc = sec_compress(streams, runner);
+    *parses_out = runner.parses;
+    *out_len = 0;
+    if (rc != 0)
+        return rc;
+    std::vector<uint8_t> whole((size_t)s.produced + 16, 0xEE);
+    for (const SecPiece &pc : s.pieces) {
+        uint8_t *o = whole.data() + pc.dst;
+        if (pc.kind == SEC_PIECE_RUN) {
+            memcpy(o, runner.outs[pc.round][pc.job].data(), pc.len);
+        } else if (pc.kind == SEC_PIECE_MARKER) {
+            o[0] = o[1] = 0;
+            o[2] = o[3] = 0xff;
+        } else if (pc.kind == SEC_PIECE_HEADER) {
+            /* what layout_buffer writes for the wrapper, from a run of nothing */
+            ZdBuf buf;
+            memset(&buf, 0, sizeof buf);
+            buf.out_cap = 64;
+            buf.level = (uint32_t)level;
+            buf.wrap = (uint32_t)wrap;
+            buf.strategy = (uint32_t)strategy;
+            buf.wbits = (uint32_t)g_wbits;
+            buf.max_blocks = 1;
+            ZdParseOut po = {0, 0};
+            ZdResult res;
+            memset(&res, 0, sizeof res);
+            uint32_t tmp[32];
+            layout_buffer(&buf, &po, nullptr, nullptr, &res, (uint8_t *)tmp);
+            memcpy(o, tmp, pc.len);
+        } else {
+            CkLds ck;
+            std::vector<uint8_t> in((size_t)n + 64, 0);
+            memcpy(in.data(), src, n);
+            const uint32_t c = wrap == 1 ? ck_adler32(in.data(), n) : ck_crc32(in.data(), n, &ck);
+            if (wrap == 1) {
+                o[0] = (uint8_t)(c >> 24), o[1] = (uint8_t)(c >> 16), o[2] = (uint8_t)(c >> 8), o[3] = (uint8_t)c;
+            } else {
+                for (int k = 0; k < 4; k++)
+                    o[k] = (uint8_t)(c >> (8 * k)), o[4 + k] = (uint8_t)(n >> (8 * k));
+            }
+        }
+    }
+    memcpy(out, whole.data(), s.delivered);
+    *out_len = s.delivered;
+    return s.status;
 }

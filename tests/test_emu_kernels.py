@@ -20,7 +20,7 @@ def emu():
 
 
 class Rec(C.Structure):
-    _fields_ = [(k, C.c_uint32) for k in ("sym_begin", "sym_count", "in_begin", "in_len", "stored_ok", "last")]
+    _fields_ = [(k, C.c_uint32) for k in ("sym_begin", "sym_count", "in_begin", "in_len", "stored_ok", "last", "cut", "data_end")]
 
 
 def emu_compress(L, data, level, wrap, strategy=0):
@@ -166,3 +166,47 @@ def test_window_bits_and_mem_level(emu, oracle):
     finally:
         emu.emu_set_params(15, 8)
         emu.emu_set_seg_mode(0)
+
+
+def emu_compress_sections(L, data, mbl, level, wb, strategy, cap, mem_level=8):
+    wrap, w = (0, -wb) if wb < 0 else (2, wb - 16) if wb > 15 else (1, wb)
+    L.emu_set_params(w, mem_level)
+    out = C.create_string_buffer(cap + 64)
+    ol, parses = C.c_uint32(), C.c_uint32()
+    rc = L.emu_compress_sections(data, len(data), mbl, level, wrap, strategy, out, cap, C.byref(ol),
+                                 C.byref(parses))
+    L.emu_set_params(15, 8)
+    return rc, out.raw[:ol.value], parses.value
+
+
+def test_sections_rounds_and_joints(emu, oracle):
+    """zsc_compress with source_len > max_block_len.  Round 0 parses every section
+    on its own; the host follows the wrapper's output slices (sections.h) and has a run parsed
+    again wherever a slice ran out at a place that lets the next section in early (finding 2).
+    The result equals the oracle's call-by-call restatement (pinned to the reference in
+    test_oracle.py), also where dest is too small and only a prefix is handed back."""
+    import random
+    rnd = random.Random(81)
+    kinds = ("text", "bitmap", "table", "random", "zero", "runs", "token", "object")
+    rejoined = 0
+    for it in range(70):
+        n = rnd.choice([300, 3000, 20000, 70000, 150000])
+        data = corpus.make_buffer(rnd.choice(kinds), n, it)
+        mbl = rnd.choice([rnd.randrange(1, 64), rnd.randrange(64, 2000), rnd.randrange(2000, 40000),
+                          rnd.randrange(20000, 100000)])
+        if mbl >= n:
+            mbl = max(1, n // rnd.randrange(2, 6))
+        if n // mbl > 300:
+            mbl = n // 300 + 1
+        lvl = rnd.choice([1, 3, 4, 6, 9])
+        wb = rnd.choice([15, 15, 31, -15, 12, 9])
+        ml = rnd.choice([8, 8, 8, 9, 5])
+        strat = rnd.choice([0, 0, 1, 4, 2, 3]) if ml >= 8 else 0   # the reference asserts on Z_FIXED + small mem_level
+        bound = oracle.max_output(n, mbl, lvl, wb, ml)[1]
+        cap = rnd.choice([bound, bound, bound + 100, max(1, bound // 2), max(1, bound // 8)])
+        want = oracle.compress(data, lvl, window_bits=wb, mem_level=ml, strategy=strat, max_block_len=mbl,
+                               dest_cap=cap, work_len=1 << 20)
+        rc, out, parses = emu_compress_sections(emu, data, mbl, lvl, wb, strat, cap, ml)
+        assert (rc, out) == (want[0], want[1]), (it, n, mbl, lvl, wb, ml, strat, cap)
+        rejoined += parses - (n + mbl - 1) // mbl
+    assert rejoined > 500   # the joints are the rule, not the exception

@@ -272,3 +272,48 @@ def test_level_0_stored(z, oracle):
     h, keep = z.gz_header_for_writing(name=b"stored.bin", hcrc=1, time=5)
     rc, out = z.compress2(bufs[2], level=0, window_bits=31, gz_header=h)
     assert rc == 0 and z.uncompress2(out, len(bufs[2]), 31)[:2] == (0, bufs[2])
+
+
+def test_sections_levels_1_to_9(z, oracle):
+    """zsc_compress with source_len > max_block_len at levels 1-9 -- sections with
+    Z_FULL_FLUSH between them, the output handed out in slices of max_block_len, and the next
+    section let in early where a slice runs out while a block is flushed (finding 2).  Golden
+    cases of the reference through zsc_compress2, then seeded cases against the oracle (pinned
+    to the reference on such cases in test_oracle.py), many streams per batched call."""
+    for c in G_DEF["sections"]:
+        data = corpus.make_buffer(c["kind"], c["size"], c["seed"])
+        rc, out = z.compress2(data, max_block_len=c["max_block_len"], level=c.get("level", 6),
+                              window_bits=c.get("window_bits", 15), strategy=c.get("strategy", 0),
+                              dest_len=c.get("dest_cap"))
+        assert (rc, len(out), sha(out)) == (c["rc"], c["out_len"], c["out_sha256"]), c
+        if rc == 0:
+            assert z.uncompress2(out, len(data), c.get("window_bits", 15))[:2] == (0, data)
+    import random
+    rnd = random.Random(82)
+    kinds = ("text", "bitmap", "table", "random", "zero", "runs", "token", "object")
+    for wb, ml, lvl, strat in ((15, 8, 6, 0), (31, 8, 9, 0), (-15, 8, 1, 0), (12, 9, 4, 1), (9, 5, 6, 0),
+                               (15, 8, 3, 4), (15, 8, 6, 3), (31, 8, 2, 2)):
+        bufs, mbls, caps = [], [], []
+        for i in range(48):
+            n = rnd.choice([300, 3000, 20000, 70000, 150000, 400000])
+            mbl = rnd.choice([rnd.randrange(1, 64), rnd.randrange(64, 2000), rnd.randrange(2000, 40000),
+                              rnd.randrange(20000, 100000), 65536, 32768])
+            if mbl >= n:
+                mbl = max(1, n // rnd.randrange(2, 6))
+            if n // mbl > 300:
+                mbl = n // 300 + 1
+            bufs.append(corpus.make_buffer(kinds[i % len(kinds)], n, 1000 * wb + i))
+            mbls.append(mbl)
+            bound = oracle.max_output(n, mbl, lvl, wb, ml)[1]
+            caps.append(rnd.choice([bound, bound, bound + 100, max(1, bound // 2), max(1, bound // 8)]))
+        rc, outs, stats = z.compress_sections_batch(bufs, mbls, lvl, wb, ml, strat, dest_caps=caps)
+        assert rc == 0, (wb, ml, lvl, strat)
+        for b, m, cap, o, s in zip(bufs, mbls, caps, outs, stats):
+            want = oracle.compress(b, lvl, window_bits=wb, mem_level=ml, strategy=strat, max_block_len=m,
+                                   dest_cap=cap, work_len=1 << 20)
+            assert (s, o) == (want[0], want[1]), (wb, ml, lvl, strat, len(b), m, cap)
+    # a caller's gzip header in front of a stream of sections
+    data = corpus.make_buffer("text", 90000, 5)
+    h, keep = z.gz_header_for_writing(name=b"sections.txt", comment=b"c" * 300, hcrc=1, time=7)
+    rc, out = z.compress2(data, max_block_len=7000, level=6, window_bits=31, gz_header=h)
+    assert rc == 0 and z.uncompress2(out, len(data), 31)[:2] == (0, data)

@@ -63,6 +63,9 @@ def _load() -> C.CDLL:
     L.zsc_hip_compress_batch.argtypes = [C.c_uint32, C.POINTER(C.c_char_p), u32p,
                                          C.POINTER(C.c_void_p), u32p, i32p, C.c_int32, C.c_int32,
                                          C.c_int32, C.c_int32]
+    L.zsc_hip_compress_sections_batch.argtypes = [C.c_uint32, C.POINTER(C.c_char_p), u32p, u32p,
+                                                  C.POINTER(C.c_void_p), u32p, i32p, C.c_int32,
+                                                  C.c_int32, C.c_int32, C.c_int32, C.c_uint32]
     L.zsc_hip_uncompress_batch.argtypes = [C.c_uint32, C.POINTER(C.c_char_p), u32p,
                                            C.POINTER(C.c_void_p), u32p, i32p, C.c_int32]
     L.zsc_hip_inflate_plan_create.argtypes = [C.POINTER(C.c_void_p), C.c_uint32, u32p, u64p, u32p,
@@ -256,6 +259,29 @@ def compress_batch(sources: Sequence[bytes], level: int = 6, window_bits: int = 
     stat = (C.c_int32 * count)()
     rc = lib.zsc_hip_compress_batch(count, srcs, slen, dsts, dlen, stat, level, window_bits,
                                     mem_level, strategy)
+    outs = [bufs[i].raw[:dlen[i]] for i in range(count)] if rc == Z_OK else []
+    return rc, outs, list(stat)
+
+
+def compress_sections_batch(sources: Sequence[bytes], max_block_lens: Sequence[int], level: int = 6,
+                            window_bits: int = DEF_WBITS, mem_level: int = DEF_MEM_LEVEL,
+                            strategy: int = Z_DEFAULT_STRATEGY,
+                            dest_caps: Optional[Sequence[int]] = None) -> Tuple[int, List[bytes], List[int]]:
+    """zsc_hip_compress_sections_batch: item i behaves like zsc_compress2 with
+    max_block_lens[i] < len(sources[i]) at levels 1-9 (sections, flush markers, output slices)."""
+    count = len(sources)
+    if dest_caps is None:
+        dest_caps = [compress_get_max_output_size2(len(s), m, level, window_bits, mem_level)[1]
+                     for s, m in zip(sources, max_block_lens)]
+    srcs = (C.c_char_p * count)(*sources)
+    slen = (C.c_uint32 * count)(*[len(s) for s in sources])
+    mbls = (C.c_uint32 * count)(*max_block_lens)
+    bufs = [C.create_string_buffer(max(c, 1)) for c in dest_caps]
+    dsts = (C.c_void_p * count)(*[C.addressof(b) for b in bufs])
+    dlen = (C.c_uint32 * count)(*dest_caps)
+    stat = (C.c_int32 * count)()
+    rc = lib.zsc_hip_compress_sections_batch(count, srcs, slen, mbls, dsts, dlen, stat, level,
+                                             window_bits, mem_level, strategy, 0)
     outs = [bufs[i].raw[:dlen[i]] for i in range(count)] if rc == Z_OK else []
     return rc, outs, list(stat)
 

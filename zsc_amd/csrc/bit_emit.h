@@ -311,7 +311,8 @@ DEV void layout_buffer(const ZdBuf *buf, const ZdParseOut *po, const ZdBlockRec 
         if (recs[i].last)
             bit = (bit + 7u) & ~7u; /* bi_windup */
     }
-    const uint32_t body_end = bit >> 3;
+    res->bits = bit - hdr_bytes * 8u;
+    const uint32_t body_end = (bit + 7u) >> 3; /* a whole number of bytes unless the run goes on (ZdBuf.more) */
     const uint32_t total = body_end + trl_bytes;
     res->out_len = total;
     if (total > buf->out_cap) {

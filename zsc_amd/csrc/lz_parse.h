@@ -72,6 +72,10 @@ typedef struct {
     ZdParseOut *out;
     ZdLevel cfg;
     uint32_t strategy;
+    uint32_t more;        /* ZdBuf.more */
+    const ZdSched *sched; /* joints of a run of sections (zsc_dev.h), in the order they are met */
+    uint32_t nsched;
+    uint32_t n0;          /* with joints: the length of the run's first section */
 } LzJob;
 
 /* wave-uniform parser state */
@@ -83,6 +87,8 @@ typedef struct {
     uint32_t nsyms, nstaged;
     uint32_t nblocks, blk_sym0, blk_in0;
     uint32_t pr_hi;     /* rank/hib are staged in LDS for positions below this */
+    uint32_t n;         /* input deflate() has been given so far (job.n unless the run has joints) */
+    uint32_t si;        /* next joint */
 } LzState;
 
 template <class L>
@@ -171,7 +177,7 @@ DEV int lz_put(const LzJob &job, L *lds, LzState &st, uint32_t sym)
 }
 
 /* FLUSH_BLOCK_ONLY, reference src/deflate.c:1660-1668 */
-DEV void lz_cut(const LzJob &job, LzState &st, uint32_t upto, uint32_t last)
+DEV void lz_cut(const LzJob &job, LzState &st, uint32_t upto, uint32_t last, uint32_t cut)
 {
     ON_LANE0
     {
@@ -182,10 +188,46 @@ DEV void lz_cut(const LzJob &job, LzState &st, uint32_t upto, uint32_t last)
         b->in_len = upto - st.blk_in0;
         b->stored_ok = st.blk_in0 >= st.base ? 1u : 0u;
         b->last = last;
+        b->cut = cut;
+        b->data_end = st.data_end;
     }
     st.nblocks++;
     st.blk_sym0 = st.nsyms;
     st.blk_in0 = upto;
+    /* a joint of kind 0: the next section was let in while this block was being flushed */
+    if (cut == ZD_CUT_FULL && st.si < job.nsched) {
+        const uint32_t jp = UNI(job.sched[st.si].pos), jk = UNI(job.sched[st.si].kind);
+        if (jk == 0u && jp == upto) {
+            st.n = UNI(job.sched[st.si].new_n);
+            st.si++;
+        }
+    }
+}
+
+/* the input given so far is used up at p: is there a joint of kind 1 here?  (The caller has
+ * sent the owed literal.)  Cuts the block if it holds anything (src/deflate.c:2118-2120) and
+ * lets the next section in. */
+DEV int lz_joint_at_end(const LzJob &job, LzState &st, uint32_t p)
+{
+    if (st.si >= job.nsched)
+        return 0;
+    if (UNI(job.sched[st.si].kind) != 1u || UNI(job.sched[st.si].pos) != p)
+        return 0;
+    if (st.nsyms != st.blk_sym0)
+        lz_cut(job, st, p, 0, ZD_CUT_END);
+    st.n = UNI(job.sched[st.si].new_n);
+    st.si++;
+    return 1;
+}
+
+/* the end of the run: FLUSH_BLOCK(s, 1) when the stream ends here (:2114-2117), else the
+ * block only if it holds anything (:2118-2120) */
+DEV void lz_cut_end(const LzJob &job, LzState &st, uint32_t p)
+{
+    if (!job.more)
+        lz_cut(job, st, p, 1, ZD_CUT_END);
+    else if (st.nsyms != st.blk_sym0)
+        lz_cut(job, st, p, 0, ZD_CUT_END);
 }
 
 /* fill_window's slide decision, reference src/deflate.c:1563-1570,1589 */
@@ -194,7 +236,7 @@ DEV void lz_refill(const LzJob &job, LzState &st, uint32_t p)
     if (p - st.base >= job.cfg.wsize + job.cfg.max_dist)
         st.base += job.cfg.wsize;
     uint64_t end = (uint64_t)st.base + 2ull * job.cfg.wsize;
-    st.data_end = end < job.n ? (uint32_t)end : job.n;
+    st.data_end = end < st.n ? (uint32_t)end : st.n;
 }
 
 /* cooperative longest-common-prefix of the strings at q and p, at most cap (<=258) bytes */
@@ -470,6 +512,8 @@ DEV void lz_parse_lazy(const LzJob &job, L *lds)
     st.nsyms = st.nstaged = 0;
     st.nblocks = st.blk_sym0 = st.blk_in0 = 0;
     st.pr_hi = 0;
+    st.n = job.nsched ? job.n0 : job.n;
+    st.si = 0;
 
     uint32_t p = 0, cur_len = 2, cur_at = 0;
     int pending = 0; /* match_available */
@@ -491,8 +535,18 @@ DEV void lz_parse_lazy(const LzJob &job, L *lds)
         if (look < ZD_MIN_LOOKAHEAD) {
             lz_refill(job, st, p);
             look = st.data_end - p;
-            if (look == 0)
-                break;
+            if (look == 0) {
+                if (st.si >= job.nsched)
+                    break;
+                /* a joint: src/deflate.c:2108-2113, then the next call carries on from here */
+                if (pending) {
+                    (void)lz_put<L>(job, lds, st, UNI(lds->ring[lz_ridx<L>(st, p - 1)]));
+                    pending = 0;
+                }
+                if (!lz_joint_at_end(job, st, p))
+                    break; /* cannot happen: the host's joints end where the run ends */
+                continue;
+            }
         }
         lz_ensure<L>(job, lds, st, p);
         lz_ensure_ranks<L>(job, lds, st, p);
@@ -568,11 +622,11 @@ DEV void lz_parse_lazy(const LzJob &job, L *lds)
             cur_len = 2;
             p += prev_len - 1;
             if (full)
-                lz_cut(job, st, p, 0);
+                lz_cut(job, st, p, 0, ZD_CUT_FULL);
         } else if (pending) {
             const uint32_t c = UNI(lds->ring[lz_ridx<L>(st, p - 1)]);
             if (lz_put<L>(job, lds, st, c))
-                lz_cut(job, st, p, 0);
+                lz_cut(job, st, p, 0, ZD_CUT_FULL);
             p++;
         } else {
             pending = 1;
@@ -581,7 +635,7 @@ DEV void lz_parse_lazy(const LzJob &job, L *lds)
     }
     if (pending)
         (void)lz_put<L>(job, lds, st, UNI(lds->ring[lz_ridx<L>(st, p - 1)]));
-    lz_cut(job, st, p, 1);
+    lz_cut_end(job, st, p);
     if (st.nstaged)
         lz_flush_stage<L>(job, lds, st);
     ON_LANE0
@@ -613,15 +667,35 @@ DEV void lz_parse_greedy(const LzJob &job, LzLdsFast *lds)
     st.nsyms = st.nstaged = 0;
     st.nblocks = st.blk_sym0 = st.blk_in0 = 0;
     st.pr_hi = 0;
+    st.n = job.nsched ? job.n0 : job.n;
+    st.si = 0;
 
     uint32_t p = 0, len = 0, at = 0;
+    uint32_t owed = 0; /* s->insert: strings at the end of a section that wait for their third byte */
     for (;;) {
         uint32_t look = st.data_end - p;
         if (look < ZD_MIN_LOOKAHEAD) {
             lz_refill(job, st, p);
             look = st.data_end - p;
-            if (look == 0)
-                break;
+            if (owed && look + owed >= 3u) {
+                /* fill_window, src/deflate.c:1591-1612: these enter the chains even where a
+                 * long match had skipped them */
+                lz_ensure<L>(job, lds, st, p);
+                uint32_t str = p - owed;
+                while (owed) {
+                    lz_mark_inserted<L>(lds, st, str);
+                    str++;
+                    owed--;
+                    if (look + owed < 3u)
+                        break;
+                }
+            }
+            if (look == 0) {
+                if (!lz_joint_at_end(job, st, p))
+                    break;
+                owed = p < 2u ? p : 2u; /* :1975 */
+                continue;
+            }
         }
         lz_ensure<L>(job, lds, st, p);
 
@@ -675,9 +749,9 @@ DEV void lz_parse_greedy(const LzJob &job, LzLdsFast *lds)
             p++;
         }
         if (full)
-            lz_cut(job, st, p, 0);
+            lz_cut(job, st, p, 0, ZD_CUT_FULL);
     }
-    lz_cut(job, st, p, 1);
+    lz_cut_end(job, st, p);
     if (st.nstaged)
         lz_flush_stage<L>(job, lds, st);
     ON_LANE0

@@ -446,6 +446,8 @@ DEV void sg_parse_segment(const LzJob &job, SgLds *lds, const SgScratch &scr, ui
     st.hi = UNI(lds->hi);
     st.wrap_base = UNI(lds->wrap_base);
     st.nsyms = st.nstaged = st.nblocks = st.blk_sym0 = st.blk_in0 = st.pr_hi = 0;
+    st.n = job.n;
+    st.si = 0;
 
     const uint32_t S0 = UNI(lds->S0);
     const uint64_t E64 = (uint64_t)S0 + SG_SPAN;
@@ -798,8 +800,12 @@ DEV void sg_append(const LzJob &job, SgOut *o, const uint32_t *tok, uint32_t fro
                 b->sym_count = job.cfg.sym_cap;
                 b->in_begin = blk_in0;
                 b->in_len = cov - blk_in0;
-                b->stored_ok = blk_in0 >= sg_base_at(job.cfg, last_start + cut_delta, job.n, need) ? 1u : 0u;
+                const uint32_t base = sg_base_at(job.cfg, last_start + cut_delta, job.n, need);
+                const uint64_t wend = (uint64_t)base + 2ull * job.cfg.wsize;
+                b->stored_ok = blk_in0 >= base ? 1u : 0u;
                 b->last = 0;
+                b->cut = ZD_CUT_FULL;
+                b->data_end = wend < job.n ? (uint32_t)wend : job.n;
             }
             nblocks++;
             blk_sym0 = nsyms;
@@ -872,15 +878,22 @@ DEV void sg_phase_resolve(const LzJob &job, SgLds *lds, const SgScratch &scr, in
         }
         ON_LANE0
         {
-            ZdBlockRec *b = &job.blocks[lds->out.nblocks];
-            b->sym_begin = lds->out.blk_sym0;
-            b->sym_count = lds->out.nsyms - lds->out.blk_sym0;
-            b->in_begin = lds->out.blk_in0;
-            b->in_len = job.n - lds->out.blk_in0;
-            b->stored_ok = lds->out.blk_in0 >= sg_base(job.cfg, job.n, job.n) ? 1u : 0u;
-            b->last = 1;
+            /* a run of sections that is not the end of its stream: Z_FULL_FLUSH, the block only
+             * if it holds anything (src/deflate.c:2118-2120) */
+            const uint32_t cutting = !job.more || lds->out.nsyms != lds->out.blk_sym0;
+            if (cutting) {
+                ZdBlockRec *b = &job.blocks[lds->out.nblocks];
+                b->sym_begin = lds->out.blk_sym0;
+                b->sym_count = lds->out.nsyms - lds->out.blk_sym0;
+                b->in_begin = lds->out.blk_in0;
+                b->in_len = job.n - lds->out.blk_in0;
+                b->stored_ok = lds->out.blk_in0 >= sg_base(job.cfg, job.n, job.n) ? 1u : 0u;
+                b->last = job.more ? 0u : 1u;
+                b->cut = ZD_CUT_END;
+                b->data_end = job.n;
+            }
             job.out->nsyms = lds->out.nsyms;
-            job.out->nblocks = lds->out.nblocks + 1;
+            job.out->nblocks = lds->out.nblocks + cutting;
             lds->redo = 0;
             lds->finished = 1;
         }

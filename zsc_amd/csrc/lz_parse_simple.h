@@ -41,15 +41,20 @@ DEV void sp_finish(const LzJob &job, SpLds *lds, uint32_t need)
 {
     ON_LANE0
     {
-        ZdBlockRec *b = &job.blocks[lds->out.nblocks];
-        b->sym_begin = lds->out.blk_sym0;
-        b->sym_count = lds->out.nsyms - lds->out.blk_sym0;
-        b->in_begin = lds->out.blk_in0;
-        b->in_len = job.n - lds->out.blk_in0;
-        b->stored_ok = lds->out.blk_in0 >= sg_base_at(job.cfg, job.n, job.n, need) ? 1u : 0u;
-        b->last = 1;
+        const uint32_t cutting = !job.more || lds->out.nsyms != lds->out.blk_sym0; /* as in sg_phase_resolve */
+        if (cutting) {
+            ZdBlockRec *b = &job.blocks[lds->out.nblocks];
+            b->sym_begin = lds->out.blk_sym0;
+            b->sym_count = lds->out.nsyms - lds->out.blk_sym0;
+            b->in_begin = lds->out.blk_in0;
+            b->in_len = job.n - lds->out.blk_in0;
+            b->stored_ok = lds->out.blk_in0 >= sg_base_at(job.cfg, job.n, job.n, need) ? 1u : 0u;
+            b->last = job.more ? 0u : 1u;
+            b->cut = ZD_CUT_END;
+            b->data_end = job.n;
+        }
         job.out->nsyms = lds->out.nsyms;
-        job.out->nblocks = lds->out.nblocks + 1;
+        job.out->nblocks = lds->out.nblocks + cutting;
     }
     WAVE_SYNC();
 }
@@ -149,6 +154,74 @@ DEV void lz_parse_rle(const LzJob &job, SpLds *lds)
         p += len;
     }
     sp_finish(job, lds, ZD_MAX_MATCH + 1u);
+}
+
+/* Both, symbol by symbol, for a run of sections with joints (zsc_dev.h ZdSched): how much input
+ * deflate() has been given changes on the way, and with it the window's slides and the
+ * lookahead that bounds a run.  Rare (an output slice of max_block_len has to run out while a
+ * block is flushed, with one of these strategies), so plain: one symbol per step, lane 0
+ * writes it. */
+DEV void lz_parse_simple_joints(const LzJob &job, SpLds *lds)
+{
+    (void)lds;
+    const int huff = job.strategy == 2u;
+    const uint32_t need = huff ? 1u : ZD_MAX_MATCH + 1u; /* :2218 / :2141 */
+    LzState st;
+    st.lo = st.hi = st.wrap_base = 0;
+    st.base = 0;
+    st.data_end = 0;
+    st.nsyms = st.nstaged = 0;
+    st.nblocks = st.blk_sym0 = st.blk_in0 = 0;
+    st.pr_hi = 0;
+    st.n = job.nsched ? job.n0 : job.n;
+    st.si = 0;
+    uint32_t p = 0;
+    for (;;) {
+        uint32_t look = st.data_end - p;
+        if (look < need) {
+            lz_refill(job, st, p);
+            look = st.data_end - p;
+            if (look == 0) {
+                if (!lz_joint_at_end(job, st, p))
+                    break;
+                continue;
+            }
+        }
+        uint32_t len = 0;
+        if (!huff && look >= 3u && p > 0u) {
+            const uint32_t prev = UNI(job.in[p - 1u]);
+            if (UNI(job.in[p]) == prev && UNI(job.in[p + 1u]) == prev && UNI(job.in[p + 2u]) == prev) {
+                const uint32_t cap = look < ZD_MAX_MATCH ? look : ZD_MAX_MATCH;
+                len = cap;
+                for (uint32_t k0 = 0; k0 < cap; k0 += WAVE) {
+                    LANEVAR(int, differs);
+                    FOR_LANES
+                    {
+                        const uint32_t k = k0 + (uint32_t)LANE;
+                        LV(differs) = k < cap && job.in[p + k] != prev;
+                    }
+                    const uint64_t dm = BALLOT(differs);
+                    if (dm != 0) {
+                        len = k0 + (uint32_t)CTZ64(dm);
+                        break;
+                    }
+                }
+            }
+        }
+        const uint32_t tok = len >= 3u ? (1u << 16) | (len - 3u) : UNI(job.in[p]);
+        ON_LANE0 { job.syms[st.nsyms] = tok; }
+        st.nsyms++;
+        p += len >= 3u ? len : 1u;
+        if (st.nsyms - st.blk_sym0 == job.cfg.sym_cap)
+            lz_cut(job, st, p, 0, ZD_CUT_FULL);
+    }
+    lz_cut_end(job, st, p);
+    ON_LANE0
+    {
+        job.out->nsyms = st.nsyms;
+        job.out->nblocks = st.nblocks;
+    }
+    WAVE_SYNC();
 }
 
 #endif

@@ -441,11 +441,27 @@ ZlibReturn zsc_compress_gzip2(U8 *dest, U32 *dest_len, const U8 *source, U32 sou
         return (ZlibReturn)stat0[0];
     }
 
-    /* what the kernels cover today; everything else fails loudly, never on a CPU path */
     if (source_len > max_block_len) {
-        ZSC_WARN("In zsc_compress_gzip2(), multi-section streams (source_len > max_block_len) "
-                 "are not offloaded yet.");
-        return Z_STREAM_ERROR;
+        /* sections with Z_FULL_FLUSH between them, and the output in slices of max_block_len
+         * (reference src/zsc_compress.c:121-138): zsc_hip_compress_sections_batch */
+        const U32 hlen = gz_header != Z_NULL ? gz_header_write(gz_header, lvl, strategy, dest, 0) : 0;
+        const U8 *srcs1[1] = {source};
+        U8 *dsts1[1] = {dest};
+        U32 slen1[1] = {source_len}, mbl1[1] = {max_block_len}, dlen1[1] = {dest_cap};
+        I32 stat1[1] = {Z_STREAM_ERROR};
+        err = zsc_hip_compress_sections_batch(1, srcs1, slen1, mbl1, dsts1, dlen1, stat1, level,
+                                              window_bits, mem_level, strategy, hlen);
+        if (err != Z_OK) {
+            return err;
+        }
+        if (gz_header != Z_NULL) {
+            (void)gz_header_write(gz_header, lvl, strategy, dest, dlen1[0] < hlen ? dlen1[0] : hlen);
+        }
+        *dest_len = dlen1[0];
+        if (stat1[0] != Z_OK) {
+            ZSC_WARN1("In zsc_compress_gzip2(), deflate loop ended with error code %d.", stat1[0]);
+        }
+        return (ZlibReturn)stat1[0];
     }
     /* A caller-supplied gzip header only changes the member header: the stream is produced
      * with the plain 10-byte header placed so that it ends where the caller's header ends,

@@ -67,7 +67,27 @@ typedef struct {
     uint32_t wrap;      /* 0 raw, 1 zlib, 2 gzip */
     uint32_t strategy;  /* 0 default, 1 filtered, 2 huffman only, 3 rle, 4 fixed */
     uint32_t wbits;     /* 9..15, for the zlib header */
+    uint32_t more;      /* 1: a run of sections that is not the end of its stream -- the last block
+                           is not final and only cut if it holds symbols (Z_FULL_FLUSH,
+                           reference src/deflate.c:2118-2120) */
+    uint32_t sched_off; /* first ZdSched of this run */
+    uint32_t sched_n;
+    uint32_t n0;        /* with joints: the length of the first section */
 } ZdBuf;
+
+/* zsc_compress with source_len > max_block_len hands deflate() the input in sections
+ * (reference src/zsc_compress.c:121-138).  A run = the sections parsed with one history.  How
+ * much of the run deflate() has been given so far grows at joints, which the host finds by
+ * following the output slices (sections.h):
+ *   kind 0  when the block that is cut at `pos` for being full has been flushed
+ *   kind 1  when the input given so far is used up (at `pos`): the owed literal goes out, the
+ *           block is cut if it holds anything, and the parse carries on with the history */
+typedef struct {
+    uint32_t pos;   /* relative to the start of the run */
+    uint32_t new_n; /* the run's length from then on */
+    uint32_t kind;
+    uint32_t pad;
+} ZdSched;
 
 /* what the parser reports per buffer */
 typedef struct {
@@ -83,7 +103,12 @@ typedef struct {
     uint32_t in_len;
     uint32_t stored_ok;
     uint32_t last;
+    uint32_t cut;      /* 0: the block was full (lit_bufsize - 1 symbols), 1: the input ended */
+    uint32_t data_end; /* how far fill_window had read when the block was cut */
 } ZdBlockRec;
+
+#define ZD_CUT_FULL 0u
+#define ZD_CUT_END 1u
 
 #define ZD_BT_STORED 0u
 #define ZD_BT_STATIC 1u
@@ -107,7 +132,7 @@ typedef struct {
     uint32_t out_len; /* bytes of the complete stream */
     int32_t status;   /* ZlibReturn */
     uint32_t adler;   /* adler32 or crc32 of the input */
-    uint32_t pad;
+    uint32_t bits;    /* bits of block data (a run that is not the end of its stream stops inside a byte) */
 } ZdResult;
 
 #endif

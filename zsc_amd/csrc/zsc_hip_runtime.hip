@@ -27,6 +27,7 @@
 #include "lz_parse.h"
 #include "lz_parse_seg.h"
 #include "lz_parse_simple.h"
+#include "sections.h"
 #include "zsc_dev.h"
 
 #include "zsc/zsc_conf_private.h"
@@ -62,7 +63,8 @@ typedef struct {
     uint64_t src_off; /* first input byte of a stored block (batch input) */
     uint64_t dst_off; /* first output byte of the piece (batch output) */
     uint32_t len;     /* stored bytes */
-    uint32_t kind;    /* 0 stored block, 1 flush marker, 2 wrapper header, 3 trailer */
+    uint32_t kind;    /* 0 stored block, 1 flush marker, 2 wrapper header, 3 trailer, 4 room for a caller's
+                         gzip header; sections.h: 5 the marker's four bytes after a run, 6 plain bytes */
     uint32_t arg;     /* block: BFINAL; header: CMF<<8|FLG or the gzip XFL; trailer / header: owning buffer */
     uint32_t buf;     /* owning buffer (for the check value) */
 } ZdStorePiece;
@@ -89,7 +91,17 @@ __global__ __launch_bounds__(256) void k_store(const uint8_t *__restrict__ in,
         const uint8_t *s = in + pc.src_off;
         for (uint32_t i = threadIdx.x; i < pc.len; i += blockDim.x)
             o[5u + i] = s[i];
+    } else if (pc.kind == 6u) {
+        const uint8_t *s = in + pc.src_off;
+        for (uint32_t i = threadIdx.x; i < pc.len; i += blockDim.x)
+            o[i] = s[i];
     } else if (threadIdx.x == 0) {
+        if (pc.kind == 5u) { /* LEN = 0, NLEN = ~0 of Z_FULL_FLUSH's empty stored block */
+            o[0] = 0;
+            o[1] = 0;
+            o[2] = 0xff;
+            o[3] = 0xff;
+        }
         if (pc.kind == 1u) { /* Z_FULL_FLUSH's empty stored block, src/deflate.c:1240-1243 */
             o[0] = 0;
             o[1] = 0;
@@ -199,6 +211,7 @@ __global__ __launch_bounds__(64) void k_parse(const uint8_t *__restrict__ in,
                                               uint32_t *__restrict__ syms,
                                               ZdBlockRec *__restrict__ recs,
                                               ZdParseOut *__restrict__ pout,
+                                              const ZdSched *__restrict__ sched,
                                               const ZdLevel cfg, uint32_t first, uint32_t nbuf)
 {
     __shared__ L lds;
@@ -218,6 +231,10 @@ __global__ __launch_bounds__(64) void k_parse(const uint8_t *__restrict__ in,
     job.out = pout + b;
     job.cfg = cfg;
     job.strategy = buf.strategy;
+    job.more = buf.more;
+    job.sched = sched + buf.sched_off;
+    job.nsched = buf.sched_n;
+    job.n0 = buf.n0;
     lz_parse_lazy<L>(job, &lds);
 }
 
@@ -262,6 +279,10 @@ __global__ __launch_bounds__(SG_W * 64, 6) void k_parse_seg(const uint8_t *__res
         job.cfg.hbits = 15u;
     }
     job.strategy = buf.strategy;
+    job.more = buf.more;
+    job.sched = nullptr; /* runs with joints go to the wave-per-buffer parser */
+    job.nsched = 0;
+    job.n0 = buf.in_len;
     SgScratch scr;
     scr.tok = seg_tok + (uint64_t)blockIdx.x * (SG_NS * SG_TOKCAP);
     scr.sidx = seg_sidx + (uint64_t)blockIdx.x * (SG_NS * SG_TRACE);
@@ -308,6 +329,7 @@ __global__ __launch_bounds__(64) void k_parse_simple(const uint8_t *__restrict__
                                                      uint32_t *__restrict__ syms,
                                                      ZdBlockRec *__restrict__ recs,
                                                      ZdParseOut *__restrict__ pout,
+                                                     const ZdSched *__restrict__ sched,
                                                      const ZdLevel cfg, uint32_t nbuf)
 {
     __shared__ SpLds lds;
@@ -327,7 +349,13 @@ __global__ __launch_bounds__(64) void k_parse_simple(const uint8_t *__restrict__
     job.out = pout + b;
     job.cfg = cfg;
     job.strategy = buf.strategy;
-    if (buf.strategy == (uint32_t)Z_HUFFMAN_ONLY)
+    job.more = buf.more;
+    job.sched = sched + buf.sched_off;
+    job.nsched = buf.sched_n;
+    job.n0 = buf.n0;
+    if (buf.sched_n)
+        lz_parse_simple_joints(job, &lds);
+    else if (buf.strategy == (uint32_t)Z_HUFFMAN_ONLY)
         lz_parse_huff(job, &lds);
     else
         lz_parse_rle(job, &lds);
@@ -343,6 +371,7 @@ __global__ __launch_bounds__(64) void k_parse_fast(const uint8_t *__restrict__ i
                                                    uint32_t *__restrict__ syms,
                                                    ZdBlockRec *__restrict__ recs,
                                                    ZdParseOut *__restrict__ pout,
+                                                   const ZdSched *__restrict__ sched,
                                                    const ZdLevel cfg, uint32_t nbuf)
 {
     __shared__ LzLdsFast lds;
@@ -362,6 +391,10 @@ __global__ __launch_bounds__(64) void k_parse_fast(const uint8_t *__restrict__ i
     job.out = pout + b;
     job.cfg = cfg;
     job.strategy = buf.strategy;
+    job.more = buf.more;
+    job.sched = sched + buf.sched_off;
+    job.nsched = buf.sched_n;
+    job.n0 = buf.n0;
     lz_parse_greedy(job, &lds);
 }
 
@@ -564,6 +597,7 @@ struct zsc_hip_deflate_plan {
     /* scratch shared by all sub-batches (sized for the largest) */
     DevBuf d_sorted, d_tmp_syms, d_rank, d_hib, d_cnt, d_dir, d_recs, d_plans, d_pout;
     DevBuf d_seg_tok, d_seg_sidx; /* per long buffer: token staging of the segmented parser */
+    DevBuf d_sched;               /* joints of runs of sections (sections.h) */
     bool use_seg = true;
     DevBuf d_res; /* one ZdResult per buffer of the whole plan */
     uint64_t rank_base_off = 0;
@@ -644,12 +678,38 @@ extern "C" ZlibReturn zsc_hip_deflate_plan_layout(U32 count, const U32 *source_l
     return Z_OK;
 }
 
+namespace {
+/* what a plan of runs of sections (sections.h) knows beyond the lengths */
+struct PlanRuns {
+    const uint32_t *more;      /* per buffer: ZdBuf.more */
+    const uint32_t *n0;        /* per buffer: length of the first section */
+    const uint32_t *sched_off; /* per buffer: first joint in sched[] */
+    const uint32_t *sched_n;
+    const ZdSched *sched;
+    uint32_t nsched;
+};
+} // namespace
+
+static ZlibReturn plan_create(zsc_hip_deflate_plan **plan_out, U32 count, const U32 *source_lens,
+                              const uint64_t *in_offsets, const uint64_t *out_offsets,
+                              const U32 *out_caps, I32 level, I32 window_bits, I32 mem_level,
+                              ZlibStrategy strategy, const PlanRuns *runs);
+
 extern "C" ZlibReturn zsc_hip_deflate_plan_create(zsc_hip_deflate_plan **plan_out, U32 count,
                                                   const U32 *source_lens,
                                                   const uint64_t *in_offsets,
                                                   const uint64_t *out_offsets, const U32 *out_caps,
                                                   I32 level, I32 window_bits, I32 mem_level,
                                                   ZlibStrategy strategy)
+{
+    return plan_create(plan_out, count, source_lens, in_offsets, out_offsets, out_caps, level,
+                       window_bits, mem_level, strategy, nullptr);
+}
+
+static ZlibReturn plan_create(zsc_hip_deflate_plan **plan_out, U32 count, const U32 *source_lens,
+                              const uint64_t *in_offsets, const uint64_t *out_offsets,
+                              const U32 *out_caps, I32 level, I32 window_bits, I32 mem_level,
+                              ZlibStrategy strategy, const PlanRuns *runs)
 {
     ZSC_ASSERT(plan_out != Z_NULL);
     *plan_out = nullptr;
@@ -678,6 +738,8 @@ extern "C" ZlibReturn zsc_hip_deflate_plan_create(zsc_hip_deflate_plan **plan_ou
         sub_limit = (uint64_t)atoll(e) << 20;
     if (sub_limit < (1ull << 20))
         sub_limit = 1ull << 20;
+    if (runs)
+        sub_limit = ~0ull; /* the caller reads the block records back: one set of scratch arrays */
 
     /* cut into sub-batches and number tiles / block slots / symbol slots inside each */
     uint64_t max_tiles = 0, max_slots = 0, max_syms = 0, max_rank_span = 0, max_count = 0;
@@ -702,6 +764,15 @@ extern "C" ZlibReturn zsc_hip_deflate_plan_create(zsc_hip_deflate_plan **plan_ou
             b.ntiles = n == 0 ? 1u : (n + ZD_TILE - 1) / ZD_TILE;
             b.tile0 = sb.ntiles;
             b.max_blocks = n / ((1u << (mem_level + 6)) - 1u) + 2;
+            if (runs) {
+                b.more = runs->more[i];
+                b.n0 = runs->n0[i];
+                b.sched_off = runs->sched_off[i];
+                b.sched_n = runs->sched_n[i];
+                b.max_blocks += b.sched_n; /* a joint can cut a block */
+            } else {
+                b.n0 = n;
+            }
             b.blk0 = sb.nslots;
             b.sym_off = sb.nsym_slots;
             b.rank_off = sb.nsym_slots; /* one u16 per (padded) input position */
@@ -776,6 +847,16 @@ extern "C" ZlibReturn zsc_hip_deflate_plan_create(zsc_hip_deflate_plan **plan_ou
     }
 
     pl->use_seg = getenv("ZSC_HIP_NO_SEG") == nullptr && kLevels[level].slow;
+    if (runs && runs->nsched) {
+        pl->use_seg = false; /* runs with joints: the wave-per-buffer parsers follow them */
+        if (!pl->d_sched.ensure(sizeof(ZdSched) * runs->nsched) ||
+            hipMemcpy(pl->d_sched.p, runs->sched, sizeof(ZdSched) * runs->nsched,
+                      hipMemcpyHostToDevice) != hipSuccess) {
+            zsc_hip_deflate_plan_destroy(pl);
+            return Z_MEM_ERROR;
+        }
+        pl->scratch_bytes += pl->d_sched.bytes;
+    }
     uint64_t max_seg = 0;
     for (const SubBatch &sb : pl->subs)
         max_seg = std::max<uint64_t>(max_seg, sb.c36);
@@ -879,15 +960,15 @@ extern "C" ZlibReturn zsc_hip_deflate_plan_run(zsc_hip_deflate_plan *pl, const v
         mark();
         if (simple) {
             hipLaunchKernelGGL(k_parse_simple, dim3(sb.count), dim3(64), 0, st, in, bufs, tmp_syms,
-                               recs, pout, cfg, sb.count);
+                               recs, pout, (const ZdSched *)pl->d_sched.p, cfg, sb.count);
             mark();
         } else if (cfg.slow) {
 #define ZSC_LAUNCH_PARSE(LT, FIRST, COUNT)                                                       \
     if ((COUNT) > 0)                                                                             \
     hipLaunchKernelGGL(k_parse<LT>, dim3(COUNT), dim3(64), 0, st, in, bufs,                      \
                        (const uint32_t *)sb.d_order.p, (const uint32_t *)sorted,                 \
-                       (const uint16_t *)rank, (const uint16_t *)hib, tmp_syms, recs, pout, cfg, \
-                       (uint32_t)(FIRST), (uint32_t)(COUNT))
+                       (const uint16_t *)rank, (const uint16_t *)hib, tmp_syms, recs, pout,      \
+                       (const ZdSched *)pl->d_sched.p, cfg, (uint32_t)(FIRST), (uint32_t)(COUNT))
             if (pl->use_seg && sb.c36 > 0) {
                 auto kern = (pl->wbits == 15 && pl->mem_level == 8) ? k_parse_seg<false> : k_parse_seg<true>;
                 hipLaunchKernelGGL(kern, dim3(sb.c36), dim3(SG_W * 64), 0, st, in, bufs,
@@ -907,7 +988,7 @@ extern "C" ZlibReturn zsc_hip_deflate_plan_run(zsc_hip_deflate_plan *pl, const v
             hipLaunchKernelGGL(k_parse_fast, dim3(sb.count), dim3(64), 0, st, in, bufs,
                                (const uint32_t *)sb.d_order.p, (const uint32_t *)sorted,
                                (const uint16_t *)rank, (const uint16_t *)hib, tmp_syms, recs,
-                               pout, cfg, sb.count);
+                               pout, (const ZdSched *)pl->d_sched.p, cfg, sb.count);
         if (!simple && !cfg.slow)
             mark(); /* levels 1-3: one parse kernel for every length, the short-buffer slot stays empty */
         mark();
@@ -1007,6 +1088,7 @@ extern "C" void zsc_hip_deflate_plan_destroy(zsc_hip_deflate_plan *pl)
     pl->d_cnt.release();
     pl->d_seg_tok.release();
     pl->d_seg_sidx.release();
+    pl->d_sched.release();
     pl->d_dir.release();
     pl->d_recs.release();
     pl->d_plans.release();
@@ -1289,6 +1371,301 @@ extern "C" ZlibReturn zsc_hip_store_batch(U32 count, const U8 *const *sources, c
     d_pieces.release();
     d_bufs.release();
     d_res.release();
+    return rc;
+}
+
+/* ---- levels 1-9 with source_len > max_block_len (sections.h) ----------------------- */
+
+namespace {
+
+/* runs the kernels for the runs sections.h wants parsed (one plan per round) and keeps every
+ * round's compressed bytes until the streams are put together */
+struct HipSecRunner {
+    const uint8_t *d_src = nullptr; /* the streams' input, stream i at src_off[i] */
+    const uint64_t *src_off = nullptr;
+    I32 level = 6, mem_level = 8;
+    int wbits = 15;
+    ZlibStrategy strategy = Z_DEFAULT_STRATEGY;
+    struct Round {
+        DevBuf d_in, d_out;
+        std::vector<uint64_t> out_off;
+    };
+    std::vector<Round *> rounds;
+    uint32_t parses = 0;
+    ZlibReturn error = Z_OK;
+
+    ~HipSecRunner()
+    {
+        for (Round *r : rounds) {
+            r->d_in.release();
+            r->d_out.release();
+            delete r;
+        }
+    }
+
+    int operator()(std::vector<SecRun *> &jobs, uint32_t round)
+    {
+        const U32 count = (U32)jobs.size();
+        std::vector<U32> lens(count), caps(count), more(count), n0(count), soff(count), scnt(count);
+        std::vector<uint64_t> in_off(count), out_off(count);
+        std::vector<ZdSched> sched;
+        for (U32 j = 0; j < count; j++) {
+            const SecRun &r = *jobs[j];
+            lens[j] = r.n;
+            more[j] = r.more ? 1u : 0u;
+            n0[j] = r.n0;
+            soff[j] = (U32)sched.size();
+            scnt[j] = (U32)r.sched.size();
+            sched.insert(sched.end(), r.sched.begin(), r.sched.end());
+        }
+        uint64_t in_bytes = 0, out_bytes = 0;
+        ZlibReturn rc = zsc_hip_deflate_plan_layout(count, lens.data(), level, -wbits, mem_level,
+                                                    in_off.data(), out_off.data(), caps.data(),
+                                                    &in_bytes, &out_bytes);
+        if (rc != Z_OK)
+            return error = rc;
+        /* every joint can cut a block, a cut costs a few bytes; room for the marker's bits */
+        out_bytes = 0;
+        for (U32 j = 0; j < count; j++) {
+            caps[j] += 16u * (scnt[j] + 1u) + 64u;
+            out_off[j] = out_bytes;
+            out_bytes += ((uint64_t)caps[j] + 16u + 15u) & ~15ull;
+        }
+        out_bytes += 64;
+        PlanRuns pr = {more.data(), n0.data(), soff.data(), scnt.data(), sched.data(), (uint32_t)sched.size()};
+        zsc_hip_deflate_plan *pl = nullptr;
+        rc = plan_create(&pl, count, lens.data(), in_off.data(), out_off.data(), caps.data(), level,
+                         -wbits, mem_level, strategy, &pr);
+        if (rc != Z_OK)
+            return error = rc;
+        Round *rd = new Round();
+        rounds.resize(round + 1, nullptr);
+        rounds[round] = rd;
+        rd->out_off = out_off;
+        DevBuf d_pieces;
+        std::vector<ZdStorePiece> gather(count);
+        for (U32 j = 0; j < count; j++) {
+            ZdStorePiece &pc = gather[j];
+            memset(&pc, 0, sizeof pc);
+            pc.src_off = src_off[jobs[j]->stream] + jobs[j]->start;
+            pc.dst_off = in_off[j];
+            pc.len = lens[j];
+            pc.kind = 6u;
+        }
+        rc = Z_OK;
+        if (!rd->d_in.ensure(in_bytes) || !rd->d_out.ensure(out_bytes) ||
+            !d_pieces.ensure(sizeof(ZdStorePiece) * count))
+            rc = Z_MEM_ERROR;
+        if (rc == Z_OK && hipMemcpy(d_pieces.p, gather.data(), sizeof(ZdStorePiece) * count,
+                                    hipMemcpyHostToDevice) != hipSuccess)
+            rc = Z_STREAM_ERROR;
+        if (rc == Z_OK) {
+            hipLaunchKernelGGL(k_store, dim3(count), dim3(256), 0, nullptr, d_src, (uint8_t *)rd->d_in.p,
+                               (const ZdStorePiece *)d_pieces.p, (const ZdBuf *)nullptr,
+                               (const ZdResult *)nullptr, count);
+            rc = zsc_hip_deflate_plan_run(pl, rd->d_in.p, rd->d_out.p, nullptr);
+        }
+        std::vector<U32> out_lens(count);
+        std::vector<I32> stat(count);
+        if (rc == Z_OK)
+            rc = zsc_hip_deflate_plan_results(pl, out_lens.data(), stat.data());
+        /* what the simulation needs of every block: where it ends, in input and in bits */
+        const SubBatch &sb = pl->subs[0];
+        std::vector<ZdBlockRec> recs(sb.nslots);
+        std::vector<uint32_t> bit_off(sb.nslots);
+        std::vector<ZdParseOut> pout(count);
+        std::vector<ZdResult> res(count);
+        if (rc == Z_OK &&
+            (hipMemcpy(recs.data(), pl->d_recs.p, sizeof(ZdBlockRec) * sb.nslots, hipMemcpyDeviceToHost) != hipSuccess ||
+             hipMemcpy2D(bit_off.data(), 4, (const uint8_t *)pl->d_plans.p + offsetof(ZdBlockPlan, bit_off),
+                         sizeof(ZdBlockPlan), 4, sb.nslots, hipMemcpyDeviceToHost) != hipSuccess ||
+             hipMemcpy(pout.data(), pl->d_pout.p, sizeof(ZdParseOut) * count, hipMemcpyDeviceToHost) != hipSuccess ||
+             hipMemcpy(res.data(), pl->d_res.p, sizeof(ZdResult) * count, hipMemcpyDeviceToHost) != hipSuccess))
+            rc = Z_STREAM_ERROR;
+        for (U32 j = 0; j < count && rc == Z_OK; j++) {
+            SecRun &r = *jobs[j];
+            const ZdBuf &b = pl->bufs[j];
+            if (stat[j] != Z_OK || pout[j].nblocks > b.max_blocks) {
+                ZSC_WARN2("zsc_hip: a run of sections came back with status %d (%u blocks).",
+                          (int)stat[j], pout[j].nblocks);
+                rc = Z_STREAM_ERROR;
+                break;
+            }
+            r.blocks.clear();
+            for (uint32_t k = 0; k < pout[j].nblocks; k++) {
+                const ZdBlockRec &rec = recs[b.blk0 + k];
+                SecBlock blk;
+                blk.upto = rec.in_begin + rec.in_len;
+                blk.end_bit = k + 1 < pout[j].nblocks ? bit_off[b.blk0 + k + 1] : res[j].bits;
+                blk.data_end = rec.data_end;
+                blk.cut = rec.cut;
+                blk.last = rec.last;
+                r.blocks.push_back(blk);
+            }
+            r.round = round;
+            r.job = j;
+        }
+        parses += count;
+        d_pieces.release();
+        rd->d_in.release(); /* only the compressed bytes are needed later */
+        zsc_hip_deflate_plan_destroy(pl);
+        return error = rc;
+    }
+};
+
+} // namespace
+
+extern "C" ZlibReturn zsc_hip_compress_sections_batch(U32 count, const U8 *const *sources,
+                                                      const U32 *source_lens, const U32 *max_block_lens,
+                                                      U8 *const *dests, U32 *dest_lens, I32 *statuses,
+                                                      I32 level, I32 window_bits, I32 mem_level,
+                                                      ZlibStrategy strategy, U32 gzip_header_len)
+{
+    ZSC_ASSERT(sources != Z_NULL);
+    ZSC_ASSERT(source_lens != Z_NULL);
+    ZSC_ASSERT(max_block_lens != Z_NULL);
+    ZSC_ASSERT(dests != Z_NULL);
+    ZSC_ASSERT(dest_lens != Z_NULL);
+    if (count == 0)
+        return Z_OK;
+    if (zsc_hip_init(-1) != Z_OK)
+        return Z_STREAM_ERROR;
+    int wrap = 1, wbits = 15;
+    if (!offloadable(level, window_bits, mem_level, strategy, &wrap, &wbits)) {
+        ZSC_WARN4("zsc_hip: level %d / window_bits %d / mem_level %d / strategy %d is not "
+                  "offloaded to the GPU yet (DESIGN.md, out of scope).",
+                  level, window_bits, mem_level, (int)strategy);
+        return Z_STREAM_ERROR;
+    }
+    if (level == Z_DEFAULT_COMPRESSION)
+        level = 6;
+
+    /* wrapper header as deflate() writes it (src/deflate.c:1031-1049, :1068-1082) */
+    uint32_t zh = (8u + (((uint32_t)wbits - 8u) << 4)) << 8;
+    const uint32_t lf = (strategy >= Z_HUFFMAN_ONLY || level < 2) ? 0u : level < 6 ? 1u : level == 6 ? 2u : 3u;
+    zh |= lf << 6;
+    zh += 31u - zh % 31u;
+    const uint32_t xfl = level == 9 ? 2u : (strategy >= Z_HUFFMAN_ONLY || level < 2) ? 4u : 0u;
+
+    std::vector<SecStream> streams(count);
+    std::vector<ZdBuf> sbufs(count);
+    std::vector<uint64_t> src_off(count);
+    uint64_t in_bytes = 0;
+    for (U32 i = 0; i < count; i++) {
+        ZSC_ASSERT(max_block_lens[i] != 0);
+        ZSC_ASSERT(sources[i] != Z_NULL);
+        SecStream &s = streams[i];
+        s.source_len = source_lens[i];
+        s.max_block_len = max_block_lens[i];
+        s.dest_cap = dest_lens[i];
+        s.wrap = wrap;
+        s.hdr_len = wrap == 1 ? 2u : wrap == 2 ? (gzip_header_len ? gzip_header_len : 10u) : 0u;
+        src_off[i] = in_bytes;
+        memset(&sbufs[i], 0, sizeof(ZdBuf));
+        sbufs[i].in_off = in_bytes;
+        sbufs[i].in_len = source_lens[i];
+        sbufs[i].wrap = (uint32_t)wrap;
+        in_bytes += ((uint64_t)source_lens[i] + 15u) & ~15ull;
+    }
+    DevBuf d_src, d_sbufs, d_sres, d_final, d_pieces;
+    ZlibReturn rc = Z_OK;
+    if (!d_src.ensure(in_bytes + 64) || !d_sbufs.ensure(sizeof(ZdBuf) * count) ||
+        !d_sres.ensure(sizeof(ZdResult) * count))
+        rc = Z_MEM_ERROR;
+    for (U32 i = 0; i < count && rc == Z_OK; i++)
+        if (source_lens[i] && hipMemcpy((uint8_t *)d_src.p + src_off[i], sources[i], source_lens[i],
+                                        hipMemcpyHostToDevice) != hipSuccess)
+            rc = Z_STREAM_ERROR;
+    if (rc == Z_OK && hipMemcpy(d_sbufs.p, sbufs.data(), sizeof(ZdBuf) * count, hipMemcpyHostToDevice) != hipSuccess)
+        rc = Z_STREAM_ERROR;
+
+    HipSecRunner runner;
+    runner.d_src = (const uint8_t *)d_src.p;
+    runner.src_off = src_off.data();
+    runner.level = level;
+    runner.mem_level = mem_level;
+    runner.wbits = wbits;
+    runner.strategy = strategy;
+    if (rc == Z_OK) {
+        const int e = sec_compress(streams, runner);
+        if (e != 0)
+            rc = runner.error != Z_OK ? runner.error : Z_STREAM_ERROR;
+    }
+
+    /* put the streams together: per round one launch that copies the runs' bytes, one for the
+     * headers / markers / trailers */
+    std::vector<uint64_t> fin_off(count);
+    uint64_t fin_bytes = 0;
+    for (U32 i = 0; i < count; i++) {
+        fin_off[i] = fin_bytes;
+        fin_bytes += ((uint64_t)streams[i].produced + 15u) & ~15ull;
+    }
+    std::vector<std::vector<ZdStorePiece>> by_round(runner.rounds.size());
+    std::vector<ZdStorePiece> small;
+    for (U32 i = 0; i < count && rc == Z_OK; i++) {
+        if (streams[i].status == SEC_Z_STREAM_ERROR) {
+            ZSC_WARN1("zsc_hip: stream %u: the runs of sections do not fit together (a bug).", i);
+            rc = Z_STREAM_ERROR;
+            break;
+        }
+        for (const SecPiece &sp : streams[i].pieces) {
+            ZdStorePiece pc;
+            memset(&pc, 0, sizeof pc);
+            pc.dst_off = fin_off[i] + sp.dst;
+            pc.len = sp.len;
+            pc.buf = i;
+            if (sp.kind == SEC_PIECE_RUN) {
+                pc.kind = 6u;
+                pc.src_off = runner.rounds[sp.round]->out_off[sp.job];
+                by_round[sp.round].push_back(pc);
+                continue;
+            }
+            if (sp.kind == SEC_PIECE_HEADER) {
+                pc.kind = wrap == 2 && gzip_header_len ? 4u : 2u; /* 4: zsc_api.c writes the caller's header */
+                pc.arg = wrap == 1 ? zh : xfl;
+            } else {
+                pc.kind = sp.kind == SEC_PIECE_MARKER ? 5u : 3u;
+            }
+            small.push_back(pc);
+        }
+    }
+    size_t most = small.size();
+    for (const std::vector<ZdStorePiece> &v : by_round)
+        most = std::max(most, v.size());
+    if (rc == Z_OK && (!d_final.ensure(fin_bytes + 64) || !d_pieces.ensure(sizeof(ZdStorePiece) * std::max<size_t>(1, most))))
+        rc = Z_MEM_ERROR;
+    if (rc == Z_OK)
+        hipLaunchKernelGGL(k_checksum, dim3(count), dim3(64), 0, nullptr, (const uint8_t *)d_src.p,
+                           (const ZdBuf *)d_sbufs.p, (ZdResult *)d_sres.p, count);
+    for (size_t r = 0; r <= by_round.size() && rc == Z_OK; r++) {
+        const std::vector<ZdStorePiece> &v = r < by_round.size() ? by_round[r] : small;
+        if (v.empty())
+            continue;
+        if (hipMemcpy(d_pieces.p, v.data(), sizeof(ZdStorePiece) * v.size(), hipMemcpyHostToDevice) != hipSuccess) {
+            rc = Z_STREAM_ERROR;
+            break;
+        }
+        const uint8_t *from = r < by_round.size() ? (const uint8_t *)runner.rounds[r]->d_out.p : (const uint8_t *)d_src.p;
+        hipLaunchKernelGGL(k_store, dim3((uint32_t)v.size()), dim3(256), 0, nullptr, from,
+                           (uint8_t *)d_final.p, (const ZdStorePiece *)d_pieces.p,
+                           (const ZdBuf *)d_sbufs.p, (const ZdResult *)d_sres.p, (uint32_t)v.size());
+        if (hipDeviceSynchronize() != hipSuccess || hipGetLastError() != hipSuccess)
+            rc = Z_STREAM_ERROR; /* d_pieces is reused by the next launch */
+    }
+    for (U32 i = 0; i < count && rc == Z_OK; i++) {
+        ZSC_ASSERT(dests[i] != Z_NULL);
+        const U32 give = streams[i].delivered;
+        if (give && hipMemcpy(dests[i], (uint8_t *)d_final.p + fin_off[i], give, hipMemcpyDeviceToHost) != hipSuccess)
+            rc = Z_STREAM_ERROR;
+        dest_lens[i] = give;
+        if (statuses)
+            statuses[i] = (I32)streams[i].status;
+    }
+    d_src.release();
+    d_sbufs.release();
+    d_sres.release();
+    d_final.release();
+    d_pieces.release();
     return rc;
 }
 
