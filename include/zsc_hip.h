@@ -32,6 +32,11 @@ I32 zsc_hip_init(I32 device_ordinal);
 /* human readable "device name | arch | CUs", valid until the next call */
 const char *zsc_hip_device_info(void);
 
+/* Device memory of finished calls and destroyed plans is kept (at most 4 GiB) for the next
+ * ones, which saves the one-shot entry points most of their hipMalloc/hipFree time; this
+ * gives it back.  ZSC_HIP_NO_CACHE=1 in the environment keeps nothing. */
+void zsc_hip_release_cached_memory(void);
+
 /* host-pointer batches ---------------------------------------------------- */
 
 /* Compress `count` independent buffers (host memory).  Item i:

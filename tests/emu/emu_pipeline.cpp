@@ -123,8 +123,11 @@ int g_seg_mode = 0; /* 0: runtime's choice, 1: force wave-per-buffer, 2: segment
                        3: segmented, first first (a parser never finds its successors' traces) */
 extern "C" void emu_set_seg_mode(int m) { g_seg_mode = m; }
 
-static void run_parse_seg(const LzJob &job, int order)
+static bool g_job_seg_ok = true; /* sections: may the segmented parser take the run with its joints? */
+
+static void run_parse_seg(const LzJob &job0, int order)
 {
+    LzJob job = job0;
     SgLds *lds = (SgLds *)malloc(sizeof(SgLds));
     memset(lds, 0x6B, sizeof(SgLds));
     std::vector<uint32_t> tok((size_t)SG_NS * SG_TOKCAP, 0xDDDDDDDD);
@@ -133,16 +136,30 @@ static void run_parse_seg(const LzJob &job, int order)
     for (int w = 0; w < SG_W; w++)
         sg_init(lds, w);
     lds->emu_ascending = order == 3;
-    while (!lds->finished) {
-        for (int w = 0; w < SG_W; w++)
-            sg_phase_begin(job, lds, w);
-        /* waves run one after the other here, so the first one drains the queue */
-        do {
-            for (int w = SG_W - 1; w >= 0; w--)
-                sg_phase_parse(job, lds, scr, w);
+    /* the phases of a run with joints, as k_parse_seg goes through them */
+    uint32_t si = 0, nph = job0.nsched ? job0.n0 : job0.n;
+    for (;;) {
+        nph = sg_phase_end(job0, nph, &si);
+        const bool goes_on = si < job0.nsched;
+        job.n = nph;
+        job.more = goes_on ? 1u : job0.more;
+        while (!lds->finished) {
             for (int w = 0; w < SG_W; w++)
-                sg_phase_resolve(job, lds, scr, w);
-        } while (lds->redo);
+                sg_phase_begin(job, lds, w);
+            /* waves run one after the other here, so the first one drains the queue */
+            do {
+                for (int w = SG_W - 1; w >= 0; w--)
+                    sg_phase_parse(job, lds, scr, w);
+                for (int w = 0; w < SG_W; w++)
+                    sg_phase_resolve(job, lds, scr, w);
+            } while (lds->redo);
+        }
+        if (!goes_on)
+            break;
+        nph = job0.sched[si].new_n;
+        si++;
+        for (int w = 0; w < SG_W; w++)
+            sg_next_phase(lds, w, job.n);
     }
     free(lds);
 }
@@ -161,7 +178,8 @@ static void run_parse(const LzJob &job)
         free(lds);
         return;
     }
-    if (job.cfg.slow && job.nsched == 0 && (g_seg_mode >= 2 || (g_seg_mode == 0 && job.n > 18432u))) {
+    if (job.cfg.slow && (job.nsched == 0 || g_job_seg_ok) &&
+        (g_seg_mode >= 2 || (g_seg_mode == 0 && job.n > 18432u))) {
         run_parse_seg(job, g_seg_mode == 3 ? 3 : 2);
         return;
     }
@@ -231,6 +249,7 @@ extern "C" int emu_parse(const uint8_t *src, uint32_t n, int level, int strategy
     job.sched = nullptr;
     job.nsched = 0;
     job.n0 = n;
+    job.ntot = n;
     run_parse(job);
     *nsyms = out.nsyms;
     *nblocks = out.nblocks;
@@ -281,6 +300,7 @@ extern "C" int emu_compress(const uint8_t *src, uint32_t n, int level, int wrap,
     job.sched = nullptr;
     job.nsched = 0;
     job.n0 = n;
+    job.ntot = n;
     run_parse(job);
 
     ZdBuf buf;
@@ -372,6 +392,8 @@ struct EmuSecRunner {
             job.sched = r.sched.data();
             job.nsched = (uint32_t)r.sched.size();
             job.n0 = r.n0;
+            job.ntot = r.n;
+            g_job_seg_ok = sec_seg_ok(r);
             run_parse(job);
             if (po.nblocks > max_blocks)
                 return -2;
@@ -408,7 +430,7 @@ struct EmuSecRunner {
                 SecBlock sb;
                 sb.upto = recs[b].in_begin + recs[b].in_len;
                 sb.end_bit = b + 1 < po.nblocks ? plans[b + 1].bit_off : res.bits;
-                sb.data_end = recs[b].data_end;
+                sb.wend = recs[b].wend;
                 sb.cut = recs[b].cut;
                 sb.last = recs[b].last;
                 r.blocks.push_back(sb);
@@ -446,6 +468,10 @@ extern "C" int emu_compress_sections(const uint8_t *src, uint32_t n, uint32_t ma
         uint8_t *o = whole.data() + pc.dst;
         if (pc.kind == SEC_PIECE_RUN) {
             memcpy(o, runner.outs[pc.round][pc.job].data(), pc.len);
+        } else if (pc.kind == SEC_PIECE_TAIL) {
+            o[0] = ((const uint8_t *)runner.outs[pc.round][pc.job].data())[pc.src] & (uint8_t)pc.mask;
+            if (pc.len > 1)
+                o[1] = 0;
         } else if (pc.kind == SEC_PIECE_MARKER) {
             o[0] = o[1] = 0;
             o[2] = o[3] = 0xff;

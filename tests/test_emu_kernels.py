@@ -20,7 +20,7 @@ def emu():
 
 
 class Rec(C.Structure):
-    _fields_ = [(k, C.c_uint32) for k in ("sym_begin", "sym_count", "in_begin", "in_len", "stored_ok", "last", "cut", "data_end")]
+    _fields_ = [(k, C.c_uint32) for k in ("sym_begin", "sym_count", "in_begin", "in_len", "stored_ok", "last", "cut", "wend")]
 
 
 def emu_compress(L, data, level, wrap, strategy=0):
@@ -209,4 +209,4 @@ def test_sections_rounds_and_joints(emu, oracle):
         rc, out, parses = emu_compress_sections(emu, data, mbl, lvl, wb, strat, cap, ml)
         assert (rc, out) == (want[0], want[1]), (it, n, mbl, lvl, wb, ml, strat, cap)
         rejoined += parses - (n + mbl - 1) // mbl
-    assert rejoined > 500   # the joints are the rule, not the exception
+    assert rejoined > 150   # runs parsed again: joints are the rule, not the exception (most are speculated)

@@ -76,6 +76,8 @@ typedef struct {
     const ZdSched *sched; /* joints of a run of sections (zsc_dev.h), in the order they are met */
     uint32_t nsched;
     uint32_t n0;          /* with joints: the length of the run's first section */
+    uint32_t ntot;        /* bytes behind `in` (= n, except while the segmented parser works through
+                             the phases of a run with joints: then n is the phase's end) */
 } LzJob;
 
 /* wave-uniform parser state */
@@ -110,12 +112,12 @@ DEV void lz_load_chunk(const LzJob &job, L *lds, LzState &st)
             uint32_t off = k + (uint32_t)LANE * 16u;
             uint32_t a = a0 + off;
             uint8_t *dst = &lds->ring[r0 + off];
-            if (a + 16 <= job.n) {
+            if (a + 16 <= job.ntot) {
                 /* 16-byte aligned: buffers start 16-byte aligned in the batch */
                 COPY16(dst, job.in + a);
             } else {
                 for (uint32_t j = 0; j < 16; j++)
-                    dst[j] = a + j < job.n ? job.in[a + j] : (uint8_t)0;
+                    dst[j] = a + j < job.ntot ? job.in[a + j] : (uint8_t)0;
             }
         }
     }
@@ -147,7 +149,7 @@ DEV void lz_load_chunk(const LzJob &job, L *lds, LzState &st)
 template <class L>
 DEV void lz_ensure(const LzJob &job, L *lds, LzState &st, uint32_t p)
 {
-    while (st.hi < job.n && st.hi < p + ZD_MIN_LOOKAHEAD)
+    while (st.hi < job.ntot && st.hi < p + ZD_MIN_LOOKAHEAD)
         lz_load_chunk<L>(job, lds, st);
 }
 
@@ -189,7 +191,8 @@ DEV void lz_cut(const LzJob &job, LzState &st, uint32_t upto, uint32_t last, uin
         b->stored_ok = st.blk_in0 >= st.base ? 1u : 0u;
         b->last = last;
         b->cut = cut;
-        b->data_end = st.data_end;
+        const uint64_t wend = (uint64_t)st.base + 2ull * job.cfg.wsize;
+        b->wend = wend < 0xffffffffull ? (uint32_t)wend : 0xffffffffu;
     }
     st.nblocks++;
     st.blk_sym0 = st.nsyms;
@@ -273,7 +276,7 @@ DEV uint32_t lz_lcp(const L *lds, const LzState &st, uint32_t q, uint32_t p, uin
 template <class L>
 DEV void lz_ensure_ranks(const LzJob &job, L *lds, LzState &st, uint32_t p)
 {
-    while (st.pr_hi < job.n && st.pr_hi < p + 384u) {
+    while (st.pr_hi < job.ntot && st.pr_hi < p + 384u) {
         FOR_LANES
         {
             uint32_t x = st.pr_hi + (uint32_t)LANE;

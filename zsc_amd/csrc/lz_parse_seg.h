@@ -141,7 +141,7 @@ DEV void sg_phase_begin(const LzJob &job, SgLds *lds, int w)
     st.wrap_base = UNI(lds->wrap_base);
     const uint32_t S0 = UNI(lds->S0);
     uint64_t want64 = (uint64_t)S0 + SG_SPAN + SG_OV + 2u * ZD_MIN_LOOKAHEAD;
-    const uint32_t want = want64 < job.n ? (uint32_t)want64 : job.n;
+    const uint32_t want = want64 < job.ntot ? (uint32_t)want64 : job.ntot;
     while (st.hi < want)
         lz_load_chunk<L>(job, lds, st);
     ON_LANE0
@@ -805,7 +805,7 @@ DEV void sg_append(const LzJob &job, SgOut *o, const uint32_t *tok, uint32_t fro
                 b->stored_ok = blk_in0 >= base ? 1u : 0u;
                 b->last = 0;
                 b->cut = ZD_CUT_FULL;
-                b->data_end = wend < job.n ? (uint32_t)wend : job.n;
+                b->wend = wend < 0xffffffffull ? (uint32_t)wend : 0xffffffffu;
             }
             nblocks++;
             blk_sym0 = nsyms;
@@ -890,16 +890,56 @@ DEV void sg_phase_resolve(const LzJob &job, SgLds *lds, const SgScratch &scr, in
                 b->stored_ok = lds->out.blk_in0 >= sg_base(job.cfg, job.n, job.n) ? 1u : 0u;
                 b->last = job.more ? 0u : 1u;
                 b->cut = ZD_CUT_END;
-                b->data_end = job.n;
+                b->wend = 0xffffffffu; /* at the end of the input everything given has been read */
+                /* a run with joints goes on from here (sg_next_phase) */
+                lds->out.nblocks++;
+                lds->out.blk_sym0 = lds->out.nsyms;
+                lds->out.blk_in0 = job.n;
             }
             job.out->nsyms = lds->out.nsyms;
-            job.out->nblocks = lds->out.nblocks + cutting;
+            job.out->nblocks = lds->out.nblocks;
             lds->redo = 0;
             lds->finished = 1;
         }
         WAVE_SYNC();
         return;
     }
+}
+
+/* A run with joints (zsc_dev.h ZdSched) is parsed in phases, each with the input given so far
+ * as its n: a joint of kind 1 is where a phase reaches its end -- the owed literal and the cut
+ * are what SG_EXIT_END does anyway -- and the next phase starts there like a super-step, with
+ * the window and the output carried over.  A joint of kind 0 only changes n, and nothing the
+ * parse did before it depends on n when the cut lies MIN_LOOKAHEAD or more before the old end
+ * (sections.h sec_seg_ok; the others go to the wave-per-buffer parser). */
+DEV void sg_next_phase(SgLds *lds, int w, uint32_t from)
+{
+    if (w != 0)
+        return;
+    ON_LANE0
+    {
+        lds->S0 = from;
+        lds->finished = 0;
+        lds->queue = 0;
+        lds->redo = 0;
+        lds->redo_seg = lds->redo_from = 0;
+        lds->chain = lds->chain_ft = 0;
+        lds->wv[0].start_p = from;
+        lds->wv[0].start_len = 2;
+        lds->wv[0].start_at = 0;
+        lds->wv[0].start_pending = 0;
+    }
+    WAVE_SYNC();
+}
+
+/* the end of the phase that starts with joint *si: joints of kind 0 are folded into it */
+DEV uint32_t sg_phase_end(const LzJob &job, uint32_t n_now, uint32_t *si)
+{
+    while (*si < job.nsched && UNI(job.sched[*si].kind) == 0u) {
+        n_now = UNI(job.sched[*si].new_n);
+        (*si)++;
+    }
+    return n_now;
 }
 
 /* before the first super-step (wave 0) */

@@ -51,7 +51,7 @@ DEV void sp_finish(const LzJob &job, SpLds *lds, uint32_t need)
             b->stored_ok = lds->out.blk_in0 >= sg_base_at(job.cfg, job.n, job.n, need) ? 1u : 0u;
             b->last = job.more ? 0u : 1u;
             b->cut = ZD_CUT_END;
-            b->data_end = job.n;
+            b->wend = 0xffffffffu;
         }
         job.out->nsyms = lds->out.nsyms;
         job.out->nblocks = lds->out.nblocks + cutting;

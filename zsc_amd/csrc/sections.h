@@ -18,13 +18,20 @@
  * maximal sequence of sections parsed with one history; a "joint" (ZdSched) is a place inside
  * a run where the next section was let in.
  *
- * The work goes in rounds.  Round 0 parses every section as a run of its own.  Then SecSim
+ * The work goes in rounds.  Round 0 parses every section as the start of a run.  Then SecSim
  * follows the calls of the wrapper and of deflate() for each stream, with the block sizes the
  * GPU found -- pure arithmetic, the counterpart of StoreSim for level 0 -- until it meets a
  * joint the run was not parsed with.  That run is parsed again in the next round, with the
- * joint (and the section it lets in); the other runs stand.  A round resolves one joint of
- * every stream that still has one; the number of rounds is the largest number of joints in
- * one stream.
+ * joint (and the section it lets in); the other runs stand.
+ *
+ * A stream needs a round per joint that way, and a parse has a long latency on a GPU.  So
+ * runs are parsed with joints of kind 1 they may not have ("speculated"): what is parsed
+ * before the end of a section does not depend on whether the run goes on behind it, so a
+ * run that turns out to end earlier than it was parsed is simply used up to there (its last
+ * byte masked: the bits behind belong to blocks that are dropped).  Round 0 gives every
+ * section one such joint when sections are short (most runs there are two sections long); a run
+ * that is parsed again gets as many as it has confirmed ones, so an incompressible stream,
+ * where every section end is a joint, takes log2(sections) rounds instead of one per section.
  *
  * Plain C++, no HIP: the kernels' lane-emulation build (tests/emu) runs the same code.
  */
@@ -43,7 +50,7 @@
 struct SecBlock {
     uint32_t upto;     /* first input position after the block (relative to the run) */
     uint32_t end_bit;  /* first bit after the block in the run's own bit stream */
-    uint32_t data_end; /* ZdBlockRec.data_end */
+    uint32_t wend;     /* ZdBlockRec.wend */
     uint32_t cut;      /* ZD_CUT_* */
     uint32_t last;
 };
@@ -55,17 +62,20 @@ struct SecRun {
     uint32_t n = 0;     /* its whole length, all known joints applied */
     bool more = false;  /* the stream goes on after it */
     std::vector<ZdSched> sched;
+    uint32_t confirmed = 0; /* joints [0, confirmed) were met by the simulation, the rest are speculated */
     /* filled in by whoever runs the kernels: */
     std::vector<SecBlock> blocks;
     uint32_t round = 0, job = 0; /* where its compressed bytes are */
 };
 
 /* the finished stream is put together from these */
-enum { SEC_PIECE_HEADER = 0, SEC_PIECE_RUN = 1, SEC_PIECE_MARKER = 2, SEC_PIECE_TRAILER = 3 };
+enum { SEC_PIECE_HEADER = 0, SEC_PIECE_RUN = 1, SEC_PIECE_MARKER = 2, SEC_PIECE_TRAILER = 3, SEC_PIECE_TAIL = 4 };
 struct SecPiece {
     uint32_t kind;
-    uint32_t round, job; /* SEC_PIECE_RUN: the first `len` bytes of that job's output */
+    uint32_t round, job; /* SEC_PIECE_RUN: the first `len` bytes of that job's output;
+                            SEC_PIECE_TAIL: byte `src` of it, AND `mask`, then len - 1 zero bytes */
     uint32_t dst, len;   /* where in the stream */
+    uint32_t src, mask;
 };
 
 struct SecStream {
@@ -114,8 +124,23 @@ struct SecSim {
         pc.job = run ? run->job : 0;
         pc.dst = dst;
         pc.len = len;
+        pc.src = pc.mask = 0;
         if (len)
             pieces.push_back(pc);
+    }
+    /* more joints of kind 1 than the simulation has met: one per section end */
+    void speculate(SecRun &r, uint32_t count)
+    {
+        while (count-- != 0 && r.start + r.n < s.source_len) {
+            ZdSched j;
+            j.pos = r.n;
+            j.new_n = r.n + std::min(s.max_block_len, s.source_len - (r.start + r.n));
+            j.kind = 1u;
+            j.pad = 0;
+            r.sched.push_back(j);
+            r.n = j.new_n;
+        }
+        r.more = r.start + r.n < s.source_len;
     }
     void take_block(const SecBlock &b)
     {
@@ -123,7 +148,7 @@ struct SecSim {
         last_end_bit = b.end_bit;
         last_upto = b.upto;
         last_cut = b.cut;
-        data_end = b.data_end;
+        data_end = std::min(b.wend, given - run_abs);
         bi++;
     }
 
@@ -192,13 +217,18 @@ struct SecSim {
                     if (avail_out == 0)
                         return SEC_Z_OK; /* need_more: the marker is never written (finding 2) */
                 }
-                if (bi != run->blocks.size() || n_cur != run->n) {
+                if ((bi != run->blocks.size() || n_cur != run->n) && si < run->confirmed) {
                     broken = true; /* the run was parsed for other joints than the ones met */
                     return SEC_Z_STREAM_ERROR;
                 }
-                /* block_done with Z_FULL_FLUSH: _tr_stored_block(s, 0, 0, 0), history forgotten */
-                const uint32_t len = (last_end_bit + 3u + 7u) >> 3;
-                piece(SEC_PIECE_RUN, run_out0, len);
+                /* block_done with Z_FULL_FLUSH: _tr_stored_block(s, 0, 0, 0), history forgotten.
+                 * The run may have been parsed further (speculated joints): its last byte can
+                 * hold bits of a block that is not used */
+                const uint32_t whole = last_end_bit >> 3, len = (last_end_bit + 3u + 7u) >> 3;
+                piece(SEC_PIECE_RUN, run_out0, whole);
+                piece(SEC_PIECE_TAIL, run_out0 + whole, len - whole);
+                pieces.back().src = whole;
+                pieces.back().mask = (1u << (last_end_bit & 7u)) - 1u;
                 piece(SEC_PIECE_MARKER, run_out0 + len, 4u);
                 produced = run_out0 + len + 4u;
                 run_abs += n_cur;
@@ -245,18 +275,23 @@ struct SecSim {
                     j.new_n = given - run_abs;
                     j.kind = last_cut == ZD_CUT_END ? 1u : 0u;
                     j.pad = 0;
-                    if (si < run->sched.size()) {
-                        const ZdSched &k = run->sched[si];
-                        if (k.pos != j.pos || k.new_n != j.new_n || k.kind != j.kind) {
-                            broken = true;
-                            err = SEC_Z_STREAM_ERROR;
-                            break;
-                        }
+                    const bool known = si < run->sched.size() && run->sched[si].pos == j.pos &&
+                                       run->sched[si].new_n == j.new_n && run->sched[si].kind == j.kind;
+                    if (known) {
                         si++;
+                        run->confirmed = std::max(run->confirmed, si);
+                    } else if (si < run->confirmed) {
+                        broken = true;
+                        err = SEC_Z_STREAM_ERROR;
+                        break;
                     } else {
+                        /* not what the run was parsed with: again, from its start, with this joint
+                         * and as many speculated ones as it has confirmed ones by now */
+                        run->sched.resize(si);
                         run->sched.push_back(j);
+                        run->confirmed = si + 1;
                         run->n = j.new_n;
-                        run->more = left_src != 0;
+                        speculate(*run, run->confirmed);
                         return run;
                     }
                 }
@@ -274,7 +309,24 @@ struct SecSim {
     }
 };
 
-/* round 0: every section a run of its own */
+/* May the segmented parser take the run?  It parses with a fixed n per phase, so a joint of
+ * kind 0 -- n grows at a cut in the middle of a phase -- must be one the parse up to the cut
+ * cannot have noticed: n only matters within MIN_LOOKAHEAD of it (lookahead caps, fill_window
+ * calls), so the cut has to lie that far before the old end. */
+static inline bool sec_seg_ok(const SecRun &r)
+{
+    uint32_t n_old = r.n0;
+    for (size_t i = 0; i < r.sched.size(); i++) {
+        if (r.sched[i].kind == 0u && r.sched[i].pos + ZD_MIN_LOOKAHEAD > n_old)
+            return false;
+        n_old = r.sched[i].new_n;
+    }
+    return true;
+}
+
+/* round 0: every section the start of a run; with short sections -- a block or two each, so
+ * that every output slice ends in a joint of kind 1 -- parsed together with the next one */
+#define SEC_SPECULATE_BELOW 65537u
 static inline void sec_first_runs(SecStream &s, uint32_t stream_index, std::vector<SecRun *> &jobs)
 {
     for (uint32_t a = 0; a < s.source_len; a += s.max_block_len) {
@@ -285,6 +337,10 @@ static inline void sec_first_runs(SecStream &s, uint32_t stream_index, std::vect
         r.more = a + r.n < s.source_len;
         SecRun &slot = s.runs[a];
         slot = r;
+        if (s.max_block_len < SEC_SPECULATE_BELOW) {
+            SecSim sim(s);
+            sim.speculate(slot, 1);
+        }
         jobs.push_back(&slot);
     }
 }

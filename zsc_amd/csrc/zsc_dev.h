@@ -73,6 +73,8 @@ typedef struct {
     uint32_t sched_off; /* first ZdSched of this run */
     uint32_t sched_n;
     uint32_t n0;        /* with joints: the length of the first section */
+    uint32_t seg_ok;    /* with joints: the segmented parser may take the run (sections.h sec_seg_ok) */
+    uint32_t pad;
 } ZdBuf;
 
 /* zsc_compress with source_len > max_block_len hands deflate() the input in sections
@@ -104,7 +106,8 @@ typedef struct {
     uint32_t stored_ok;
     uint32_t last;
     uint32_t cut;      /* 0: the block was full (lit_bufsize - 1 symbols), 1: the input ended */
-    uint32_t data_end; /* how far fill_window had read when the block was cut */
+    uint32_t wend;     /* end of the window (base + 2 * w_size) when the block was cut: fill_window had
+                          read up to there, or to the end of the input given so far if that is less */
 } ZdBlockRec;
 
 #define ZD_CUT_FULL 0u

@@ -64,7 +64,8 @@ typedef struct {
     uint64_t dst_off; /* first output byte of the piece (batch output) */
     uint32_t len;     /* stored bytes */
     uint32_t kind;    /* 0 stored block, 1 flush marker, 2 wrapper header, 3 trailer, 4 room for a caller's
-                         gzip header; sections.h: 5 the marker's four bytes after a run, 6 plain bytes */
+                         gzip header; sections.h: 5 the marker's four bytes after a run, 6 plain bytes,
+                         7 one byte AND arg, then len - 1 zero bytes (the end of a run) */
     uint32_t arg;     /* block: BFINAL; header: CMF<<8|FLG or the gzip XFL; trailer / header: owning buffer */
     uint32_t buf;     /* owning buffer (for the check value) */
 } ZdStorePiece;
@@ -96,6 +97,11 @@ __global__ __launch_bounds__(256) void k_store(const uint8_t *__restrict__ in,
         for (uint32_t i = threadIdx.x; i < pc.len; i += blockDim.x)
             o[i] = s[i];
     } else if (threadIdx.x == 0) {
+        if (pc.kind == 7u) {
+            o[0] = in[pc.src_off] & (uint8_t)pc.arg;
+            if (pc.len > 1u)
+                o[1] = 0;
+        }
         if (pc.kind == 5u) { /* LEN = 0, NLEN = ~0 of Z_FULL_FLUSH's empty stored block */
             o[0] = 0;
             o[1] = 0;
@@ -222,6 +228,7 @@ __global__ __launch_bounds__(64) void k_parse(const uint8_t *__restrict__ in,
     LzJob job;
     job.in = in + buf.in_off;
     job.n = buf.in_len;
+    job.ntot = buf.in_len;
     job.sorted = sorted + (uint64_t)buf.tile0 * ZD_TILE;
     job.rank = rank + buf.rank_off;
     job.hib = hib + buf.rank_off;
@@ -253,6 +260,7 @@ __global__ __launch_bounds__(SG_W * 64, 6) void k_parse_seg(const uint8_t *__res
                                                          ZdParseOut *__restrict__ pout,
                                                          uint32_t *__restrict__ seg_tok,
                                                          uint16_t *__restrict__ seg_sidx,
+                                                         const ZdSched *__restrict__ sched,
                                                          const ZdLevel cfg, uint32_t first,
                                                          uint32_t nbuf)
 {
@@ -264,6 +272,7 @@ __global__ __launch_bounds__(SG_W * 64, 6) void k_parse_seg(const uint8_t *__res
     LzJob job;
     job.in = in + buf.in_off;
     job.n = buf.in_len;
+    job.ntot = buf.in_len;
     job.sorted = sorted + (uint64_t)buf.tile0 * ZD_TILE;
     job.rank = rank + buf.rank_off;
     job.hib = hib + buf.rank_off;
@@ -280,42 +289,57 @@ __global__ __launch_bounds__(SG_W * 64, 6) void k_parse_seg(const uint8_t *__res
     }
     job.strategy = buf.strategy;
     job.more = buf.more;
-    job.sched = nullptr; /* runs with joints go to the wave-per-buffer parser */
-    job.nsched = 0;
-    job.n0 = buf.in_len;
+    job.sched = sched + buf.sched_off;
+    job.nsched = buf.sched_n;
+    job.n0 = buf.n0;
     SgScratch scr;
     scr.tok = seg_tok + (uint64_t)blockIdx.x * (SG_NS * SG_TOKCAP);
     scr.sidx = seg_sidx + (uint64_t)blockIdx.x * (SG_NS * SG_TRACE);
     const int w = (int)(threadIdx.x >> 6);
     sg_init(&lds, w);
     __syncthreads();
-    /* every loop is bounded so that a logic error can never hang the device: a buffer
-     * needs n/SG_SPAN + 1 super-steps */
+    /* every loop is bounded so that a logic error can never hang the device: a phase needs
+     * n/SG_SPAN + 1 super-steps, a run has at most one phase per joint and one more */
     const uint32_t max_steps = buf.in_len / SG_SPAN + 2;
-    uint32_t steps = 0;
     bool stuck = false;
-    while (!lds.finished) {
-        if (++steps > max_steps) {
-            stuck = true;
-            break;
-        }
-        sg_phase_begin(job, &lds, w);
-        __syncthreads();
-        /* a redo round follows whenever a parser gave up before it met a successor's
-         * tokens; each one moves the resolver at least one segment on */
-        uint32_t rounds = 0;
-        do {
-            if (++rounds > SG_NS + 1) {
+    uint32_t si = 0, nph = buf.sched_n ? buf.n0 : buf.in_len;
+    for (uint32_t phase = 0; phase <= buf.sched_n && !stuck; phase++) {
+        nph = sg_phase_end(job, nph, &si); /* joints of kind 0 only move the end (lz_parse_seg.h) */
+        const bool goes_on = si < buf.sched_n;
+        job.n = nph;
+        job.more = goes_on ? 1u : buf.more;
+        uint32_t steps = 0;
+        while (!lds.finished) {
+            if (++steps > max_steps) {
                 stuck = true;
                 break;
             }
-            sg_phase_parse(job, &lds, scr, w);
+            sg_phase_begin(job, &lds, w);
             __syncthreads();
-            sg_phase_resolve(job, &lds, scr, w);
-            __syncthreads();
-        } while (lds.redo);
-        if (stuck)
+            /* a redo round follows whenever a parser gave up before it met a successor's
+             * tokens; each one moves the resolver at least one segment on */
+            uint32_t rounds = 0;
+            do {
+                if (++rounds > SG_NS + 1) {
+                    stuck = true;
+                    break;
+                }
+                sg_phase_parse(job, &lds, scr, w);
+                __syncthreads();
+                sg_phase_resolve(job, &lds, scr, w);
+                __syncthreads();
+            } while (lds.redo);
+            if (stuck)
+                break;
+        }
+        if (!goes_on)
             break;
+        /* every wave must have seen lds.finished before wave 0 clears it for the next phase */
+        __syncthreads();
+        nph = sched[buf.sched_off + si].new_n;
+        si++;
+        sg_next_phase(&lds, w, job.n);
+        __syncthreads();
     }
     if (stuck && threadIdx.x == 0) {
         job.out->nsyms = 0;
@@ -340,6 +364,7 @@ __global__ __launch_bounds__(64) void k_parse_simple(const uint8_t *__restrict__
     LzJob job;
     job.in = in + buf.in_off;
     job.n = buf.in_len;
+    job.ntot = buf.in_len;
     job.sorted = nullptr;
     job.rank = nullptr;
     job.hib = nullptr;
@@ -382,6 +407,7 @@ __global__ __launch_bounds__(64) void k_parse_fast(const uint8_t *__restrict__ i
     LzJob job;
     job.in = in + buf.in_off;
     job.n = buf.in_len;
+    job.ntot = buf.in_len;
     job.sorted = sorted + (uint64_t)buf.tile0 * ZD_TILE;
     job.rank = rank + buf.rank_off;
     job.hib = hib + buf.rank_off;
@@ -548,6 +574,55 @@ void do_init(int ordinal)
     g_init_status = Z_OK;
 }
 
+/* Freed device blocks, kept for the next plan.  The one-shot entry points (zsc_compress ...)
+ * build and drop a plan per call and the sections path one per round; hipMalloc / hipFree cost
+ * a tenth of a millisecond each and hipFree waits for the device.  At most kMaxHeld bytes in
+ * kMaxBlocks blocks are kept (ZSC_HIP_NO_CACHE: none); a block serves a request of at least
+ * half its size. */
+struct DevCache {
+    static constexpr size_t kMaxHeld = 4ull << 30, kMaxBlocks = 96;
+    std::mutex mu;
+    std::vector<std::pair<size_t, void *>> blocks;
+    size_t held = 0;
+    bool off = getenv("ZSC_HIP_NO_CACHE") != nullptr;
+
+    void *take(size_t need, size_t *got)
+    {
+        std::lock_guard<std::mutex> lock(mu);
+        size_t best = blocks.size();
+        for (size_t i = 0; i < blocks.size(); i++)
+            if (blocks[i].first >= need && blocks[i].first <= 2 * need + (1u << 16) &&
+                (best == blocks.size() || blocks[i].first < blocks[best].first))
+                best = i;
+        if (best == blocks.size())
+            return nullptr;
+        void *p = blocks[best].second;
+        *got = blocks[best].first;
+        held -= blocks[best].first;
+        blocks[best] = blocks.back();
+        blocks.pop_back();
+        return p;
+    }
+    bool give(void *p, size_t bytes)
+    {
+        std::lock_guard<std::mutex> lock(mu);
+        if (off || blocks.size() >= kMaxBlocks || held + bytes > kMaxHeld)
+            return false;
+        blocks.push_back(std::make_pair(bytes, p));
+        held += bytes;
+        return true;
+    }
+    void trim()
+    {
+        std::lock_guard<std::mutex> lock(mu);
+        for (auto &b : blocks)
+            (void)hipFree(b.second);
+        blocks.clear();
+        held = 0;
+    }
+};
+DevCache g_dev_cache;
+
 struct DevBuf {
     void *p = nullptr;
     size_t bytes = 0;
@@ -555,20 +630,27 @@ struct DevBuf {
     {
         if (need <= bytes)
             return true;
+        release();
+        if (need == 0)
+            need = 16;
+        p = g_dev_cache.take(need, &bytes);
         if (p)
-            (void)hipFree(p);
-        p = nullptr;
-        bytes = 0;
+            return true;
         if (hipMalloc(&p, need) != hipSuccess) {
-            ZSC_WARN1("zsc_hip: hipMalloc of %zu bytes failed.", need);
-            return false;
+            g_dev_cache.trim(); /* what is kept may be what is missing */
+            if (hipMalloc(&p, need) != hipSuccess) {
+                p = nullptr;
+                ZSC_WARN1("zsc_hip: hipMalloc of %zu bytes failed.", need);
+                return false;
+            }
         }
         bytes = need;
         return true;
     }
+    /* the caller has waited for the work that used the block */
     void release()
     {
-        if (p)
+        if (p && !g_dev_cache.give(p, bytes))
             (void)hipFree(p);
         p = nullptr;
         bytes = 0;
@@ -584,6 +666,7 @@ struct SubBatch {
     /* the length-sorted order (longest first) splits into ring-size classes:
      * [0,c36) full ring, [c36,c16) <= 18 432 B, [c16,c8) <= 10 240 B, [c8,count) <= 6 144 B */
     uint32_t c36 = 0, c16 = 0, c8 = 0;
+    uint32_t cseg = 0; /* [0,cseg) of the full-ring class go to the segmented parser */
 };
 
 } // namespace
@@ -614,6 +697,11 @@ extern "C" I32 zsc_hip_init(I32 device_ordinal)
 {
     std::call_once(g_init_once, do_init, (int)device_ordinal);
     return g_init_status;
+}
+
+extern "C" void zsc_hip_release_cached_memory(void)
+{
+    g_dev_cache.trim();
 }
 
 extern "C" const char *zsc_hip_device_info(void)
@@ -685,6 +773,7 @@ struct PlanRuns {
     const uint32_t *n0;        /* per buffer: length of the first section */
     const uint32_t *sched_off; /* per buffer: first joint in sched[] */
     const uint32_t *sched_n;
+    const uint32_t *seg_ok;    /* per buffer: sections.h sec_seg_ok */
     const ZdSched *sched;
     uint32_t nsched;
 };
@@ -769,6 +858,7 @@ static ZlibReturn plan_create(zsc_hip_deflate_plan **plan_out, U32 count, const 
                 b.n0 = runs->n0[i];
                 b.sched_off = runs->sched_off[i];
                 b.sched_n = runs->sched_n[i];
+                b.seg_ok = runs->seg_ok[i];
                 b.max_blocks += b.sched_n; /* a joint can cut a block */
             } else {
                 b.n0 = n;
@@ -795,6 +885,7 @@ static ZlibReturn plan_create(zsc_hip_deflate_plan **plan_out, U32 count, const 
         pl->subs.push_back(std::move(sb));
     }
 
+    pl->use_seg = getenv("ZSC_HIP_NO_SEG") == nullptr && kLevels[level].slow;
     /* per-sub-batch descriptor arrays */
     for (SubBatch &sb : pl->subs) {
         std::vector<uint32_t> tile_owner(sb.ntiles), blk_owner(sb.nslots), order(sb.count);
@@ -806,13 +897,24 @@ static ZlibReturn plan_create(zsc_hip_deflate_plan **plan_out, U32 count, const 
                 blk_owner[b.blk0 + s] = k;
             order[k] = k;
         }
+        /* longest first; among the long ones, those the segmented parser may take come first */
+        auto seg_able = [&](uint32_t k) {
+            const ZdBuf &b = pl->bufs[sb.first + k];
+            return pl->use_seg && b.in_len > 18432u && (b.sched_n == 0 || b.seg_ok);
+        };
         std::stable_sort(order.begin(), order.end(), [&](uint32_t a, uint32_t c) {
+            const bool sa = seg_able(a), sc = seg_able(c);
+            if (sa != sc)
+                return sa;
             return pl->bufs[sb.first + a].in_len > pl->bufs[sb.first + c].in_len;
         });
         {
             const bool full_only = getenv("ZSC_HIP_FULL_RING") != nullptr;
             uint32_t k = 0;
             auto len_at = [&](uint32_t idx) { return pl->bufs[sb.first + order[idx]].in_len; };
+            while (k < sb.count && seg_able(order[k]))
+                k++;
+            sb.cseg = k;
             while (k < sb.count && (full_only || len_at(k) > 18432u))
                 k++;
             sb.c36 = k;
@@ -846,9 +948,7 @@ static ZlibReturn plan_create(zsc_hip_deflate_plan **plan_out, U32 count, const 
                              sb.d_order.bytes;
     }
 
-    pl->use_seg = getenv("ZSC_HIP_NO_SEG") == nullptr && kLevels[level].slow;
     if (runs && runs->nsched) {
-        pl->use_seg = false; /* runs with joints: the wave-per-buffer parsers follow them */
         if (!pl->d_sched.ensure(sizeof(ZdSched) * runs->nsched) ||
             hipMemcpy(pl->d_sched.p, runs->sched, sizeof(ZdSched) * runs->nsched,
                       hipMemcpyHostToDevice) != hipSuccess) {
@@ -859,7 +959,7 @@ static ZlibReturn plan_create(zsc_hip_deflate_plan **plan_out, U32 count, const 
     }
     uint64_t max_seg = 0;
     for (const SubBatch &sb : pl->subs)
-        max_seg = std::max<uint64_t>(max_seg, sb.c36);
+        max_seg = std::max<uint64_t>(max_seg, sb.cseg);
     if (pl->use_seg && max_seg) {
         if (!pl->d_seg_tok.ensure(max_seg * SG_NS * SG_TOKCAP * 4ull) ||
             !pl->d_seg_sidx.ensure(max_seg * SG_NS * SG_TRACE * 2ull)) {
@@ -969,16 +1069,16 @@ extern "C" ZlibReturn zsc_hip_deflate_plan_run(zsc_hip_deflate_plan *pl, const v
                        (const uint32_t *)sb.d_order.p, (const uint32_t *)sorted,                 \
                        (const uint16_t *)rank, (const uint16_t *)hib, tmp_syms, recs, pout,      \
                        (const ZdSched *)pl->d_sched.p, cfg, (uint32_t)(FIRST), (uint32_t)(COUNT))
-            if (pl->use_seg && sb.c36 > 0) {
+            if (sb.cseg > 0) {
                 auto kern = (pl->wbits == 15 && pl->mem_level == 8) ? k_parse_seg<false> : k_parse_seg<true>;
-                hipLaunchKernelGGL(kern, dim3(sb.c36), dim3(SG_W * 64), 0, st, in, bufs,
+                hipLaunchKernelGGL(kern, dim3(sb.cseg), dim3(SG_W * 64), 0, st, in, bufs,
                                    (const uint32_t *)sb.d_order.p, (const uint32_t *)sorted,
                                    (const uint16_t *)rank, (const uint16_t *)hib,
                                    (const uint32_t *)cnt, tmp_syms, recs,
                                    pout, (uint32_t *)pl->d_seg_tok.p, (uint16_t *)pl->d_seg_sidx.p,
-                                   cfg, 0u, sb.c36);
-            } else
-                ZSC_LAUNCH_PARSE(LzLds, 0, sb.c36);
+                                   (const ZdSched *)pl->d_sched.p, cfg, 0u, sb.cseg);
+            }
+            ZSC_LAUNCH_PARSE(LzLds, sb.cseg, sb.c36 - sb.cseg);
             mark();
             ZSC_LAUNCH_PARSE(LzLds16k, sb.c36, sb.c16 - sb.c36);
             ZSC_LAUNCH_PARSE(LzLds8k, sb.c16, sb.c8 - sb.c16);
@@ -1075,6 +1175,7 @@ extern "C" void zsc_hip_deflate_plan_destroy(zsc_hip_deflate_plan *pl)
 {
     if (!pl)
         return;
+    (void)hipStreamSynchronize(pl->last_stream); /* the blocks go back to the cache, not to hipFree */
     for (SubBatch &sb : pl->subs) {
         sb.d_bufs.release();
         sb.d_tile_owner.release();
@@ -1406,7 +1507,7 @@ struct HipSecRunner {
     int operator()(std::vector<SecRun *> &jobs, uint32_t round)
     {
         const U32 count = (U32)jobs.size();
-        std::vector<U32> lens(count), caps(count), more(count), n0(count), soff(count), scnt(count);
+        std::vector<U32> lens(count), caps(count), more(count), n0(count), soff(count), scnt(count), segok(count);
         std::vector<uint64_t> in_off(count), out_off(count);
         std::vector<ZdSched> sched;
         for (U32 j = 0; j < count; j++) {
@@ -1416,6 +1517,7 @@ struct HipSecRunner {
             n0[j] = r.n0;
             soff[j] = (U32)sched.size();
             scnt[j] = (U32)r.sched.size();
+            segok[j] = sec_seg_ok(r) ? 1u : 0u;
             sched.insert(sched.end(), r.sched.begin(), r.sched.end());
         }
         uint64_t in_bytes = 0, out_bytes = 0;
@@ -1432,7 +1534,7 @@ struct HipSecRunner {
             out_bytes += ((uint64_t)caps[j] + 16u + 15u) & ~15ull;
         }
         out_bytes += 64;
-        PlanRuns pr = {more.data(), n0.data(), soff.data(), scnt.data(), sched.data(), (uint32_t)sched.size()};
+        PlanRuns pr = {more.data(), n0.data(), soff.data(), scnt.data(), segok.data(), sched.data(), (uint32_t)sched.size()};
         zsc_hip_deflate_plan *pl = nullptr;
         rc = plan_create(&pl, count, lens.data(), in_off.data(), out_off.data(), caps.data(), level,
                          -wbits, mem_level, strategy, &pr);
@@ -1497,7 +1599,7 @@ struct HipSecRunner {
                 SecBlock blk;
                 blk.upto = rec.in_begin + rec.in_len;
                 blk.end_bit = k + 1 < pout[j].nblocks ? bit_off[b.blk0 + k + 1] : res[j].bits;
-                blk.data_end = rec.data_end;
+                blk.wend = rec.wend;
                 blk.cut = rec.cut;
                 blk.last = rec.last;
                 r.blocks.push_back(blk);
@@ -1614,9 +1716,10 @@ extern "C" ZlibReturn zsc_hip_compress_sections_batch(U32 count, const U8 *const
             pc.dst_off = fin_off[i] + sp.dst;
             pc.len = sp.len;
             pc.buf = i;
-            if (sp.kind == SEC_PIECE_RUN) {
-                pc.kind = 6u;
-                pc.src_off = runner.rounds[sp.round]->out_off[sp.job];
+            if (sp.kind == SEC_PIECE_RUN || sp.kind == SEC_PIECE_TAIL) {
+                pc.kind = sp.kind == SEC_PIECE_RUN ? 6u : 7u;
+                pc.src_off = runner.rounds[sp.round]->out_off[sp.job] + sp.src;
+                pc.arg = sp.mask;
                 by_round[sp.round].push_back(pc);
                 continue;
             }
@@ -1881,6 +1984,7 @@ extern "C" void zsc_hip_inflate_plan_destroy(zsc_hip_inflate_plan *pl)
 {
     if (!pl)
         return;
+    (void)hipStreamSynchronize(pl->last_stream);
     pl->d_items.release();
     pl->d_order.release();
     pl->d_res.release();
