@@ -442,6 +442,9 @@ struct EmuSecRunner {
     }
 };
 
+static uint32_t g_gz_hdr_len = 0; /* emu_set_gz_header_len: a caller's gzip header of this length (0: the plain one) */
+extern "C" void emu_set_gz_header_len(uint32_t n) { g_gz_hdr_len = n; }
+
 /* returns the call's ZlibReturn; *rounds_out / *parses_out tell how much work it took */
 extern "C" int emu_compress_sections(const uint8_t *src, uint32_t n, uint32_t max_block_len, int level,
                                      int wrap, int strategy, uint8_t *out, uint32_t dest_cap,
@@ -453,7 +456,7 @@ extern "C" int emu_compress_sections(const uint8_t *src, uint32_t n, uint32_t ma
     s.max_block_len = max_block_len;
     s.dest_cap = dest_cap;
     s.wrap = wrap;
-    s.hdr_len = wrap == 1 ? 2u : wrap == 2 ? 10u : 0u;
+    s.hdr_len = wrap == 1 ? 2u : wrap == 2 ? (g_gz_hdr_len ? g_gz_hdr_len : 10u) : 0u;
     EmuSecRunner runner;
     runner.src = src;
     runner.level = level;
@@ -490,7 +493,10 @@ extern "C" int emu_compress_sections(const uint8_t *src, uint32_t n, uint32_t ma
             memset(&res, 0, sizeof res);
             uint32_t tmp[32];
             layout_buffer(&buf, &po, nullptr, nullptr, &res, (uint8_t *)tmp);
-            memcpy(o, tmp, pc.len);
+            if (wrap == 2 && g_gz_hdr_len)
+                memset(o, 0xAA, pc.len); /* zsc_api.c writes the caller's header there */
+            else
+                memcpy(o, tmp, pc.len);
         } else {
             CkLds ck;
             std::vector<uint8_t> in((size_t)n + 64, 0);

@@ -177,6 +177,23 @@ def main():
                     rc3, o3 = R.compress(d3, lvl, window_bits=31, gz_header=h, dest_cap=cap)
                     case.setdefault("small_dest", []).append({"cap": cap, "rc": rc3, "out_hex": o3.hex()})
             gzh.append(case)
+    # a caller's header in front of a stream of sections: its length moves every output slice
+    gz_sections = []
+    for k, kw in enumerate(({"name": b"hello.txt", "time": 5},
+                            {"extra": bytes(range(200)) * 3, "name": b"x" * 100, "comment": b"y" * 200, "hcrc": 1})):
+        hlen = 10 + (2 + len(kw["extra"]) if "extra" in kw else 0) + (len(kw["name"]) + 1 if "name" in kw else 0) \
+            + (len(kw["comment"]) + 1 if "comment" in kw else 0) + (2 if kw.get("hcrc") else 0)
+        for kind, size in (("text", 90000), ("random", 20000)):
+            d5 = corpus.make_buffer(kind, size, 5)
+            for mbl, lvl, cap in ((7000, 6, None), (300, 1, None), (32768, 9, None), (7000, 0, None),
+                                  (7000, 6, hlen + 5000), (300, 6, hlen - 3)):
+                h, keep = gz_header_for_writing(**kw)
+                if cap is None:  # the slices depend on how much dest is left: say it
+                    cap = R.max_output(size, mbl, lvl, 31)[1] + hlen + 100
+                rc, out = R.compress(d5, lvl, window_bits=31, max_block_len=mbl, gz_header=h, dest_cap=cap)
+                gz_sections.append({"header": k, "kind": kind, "size": size, "max_block_len": mbl, "level": lvl,
+                                    "dest_cap": cap, "rc": rc,
+                                    "out_len": len(out), "out_sha256": sha(out)})
     hr, bufs = gz_header_for_reading(10, 10, 10)
     zl = R.compress(d3, 6, window_bits=15)[1]
     rc2, o2, used = R.uncompress(zl, len(d3), 47, gz_header=hr)
@@ -291,7 +308,7 @@ def main():
                        "cases": cases})
     json.dump({"deflate": deflate_cases, "streams": streams, "params": params, "small": small,
                "sections": sections, "strategies": strategies,
-               "gz_header": gzh, "gz_header_misc": gz_misc, "stored": stored}, open(os.path.join(HERE, "deflate_golden.json"), "w"), indent=0)
+               "gz_header": gzh, "gz_header_misc": gz_misc, "gz_header_sections": gz_sections, "stored": stored}, open(os.path.join(HERE, "deflate_golden.json"), "w"), indent=0)
     json.dump({"checksums": sums, "inflate_kat": kats, "corrupt": corrupt, "resync": resync,
                "corrupt_source": {"kind": "text", "size": 20000, "seed": 3, "level": 6}},
               open(os.path.join(HERE, "inflate_golden.json"), "w"), indent=0)

@@ -317,3 +317,16 @@ def test_sections_levels_1_to_9(z, oracle):
     h, keep = z.gz_header_for_writing(name=b"sections.txt", comment=b"c" * 300, hcrc=1, time=7)
     rc, out = z.compress2(data, max_block_len=7000, level=6, window_bits=31, gz_header=h)
     assert rc == 0 and z.uncompress2(out, len(data), 31)[:2] == (0, data)
+
+
+def test_sections_behind_a_callers_gzip_header(z):
+    """The length of a caller's gzip member header moves every output slice of a stream of
+    sections (levels 0-9); outcomes recorded from the reference."""
+    heads = ({"name": b"hello.txt", "time": 5},
+             {"extra": bytes(range(200)) * 3, "name": b"x" * 100, "comment": b"y" * 200, "hcrc": 1})
+    for c in G_DEF["gz_header_sections"]:
+        data = corpus.make_buffer(c["kind"], c["size"], 5)
+        h, keep = z.gz_header_for_writing(**heads[c["header"]])
+        rc, out = z.compress2(data, max_block_len=c["max_block_len"], level=c["level"], window_bits=31,
+                              gz_header=h, dest_len=c["dest_cap"])
+        assert (rc, len(out), sha(out)) == (c["rc"], c["out_len"], c["out_sha256"]), c
