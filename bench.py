@@ -87,6 +87,9 @@ def main() -> None:
     ap.add_argument("--verify", type=int, default=1, help="buffers per rank checked against the oracle")
     ap.add_argument("--with-inflate", action="store_true",
                     help="also time the inflate kernel on the produced streams (extra field)")
+    ap.add_argument("--max-block-len", type=int, default=0,
+                    help="also time the same buffers as streams of sections of this length "
+                         "(zsc_compress with max_block_len < source_len; extra field)")
     args = ap.parse_args()
 
     import torch
@@ -206,6 +209,34 @@ def main() -> None:
         ip.close()
         del d_src, d_dst
 
+    # ---- the same buffers as streams of sections, reported beside the headline
+    sections_info = None
+    if args.max_block_len > 0:
+        mbl = args.max_block_len
+        caps = [zsc_amd.compress_get_max_output_size2(n, mbl, args.level)[1] for n in my_lens]
+        ooff, o = [], 0
+        for c in caps:
+            ooff.append(o)
+            o += (c + 15) & ~15
+        d_sec = torch.empty(o + 64, dtype=torch.uint8, device=dev)
+        call = lambda: zsc_amd.compress_sections_device(d_in.data_ptr(), plan.in_offsets[:len(my_lens)], my_lens,
+                                                        [mbl] * len(my_lens), d_sec.data_ptr(), ooff, caps, args.level)
+        call()
+        fence()
+        t1 = time.perf_counter()
+        rc, slens, sstat = call()
+        fence()
+        wall = time.perf_counter() - t1
+        k = 3 % len(period_bufs)
+        got = bytes(d_sec[ooff[k]:ooff[k] + slens[k]].cpu().numpy())
+        want = oracle.compress(period_bufs[k], args.level, max_block_len=mbl, dest_cap=caps[k])
+        sections_info = {"max_block_len": mbl, "MB_per_s_in": round(in_bytes_rank / wall / 1e6, 2),
+                         "wall_ms": round(wall * 1e3, 3), "compressed_bytes": sum(slens),
+                         "all_ok": bool(rc == 0 and all(x == 0 for x in sstat) and (want[0], want[1]) == (0, got)),
+                         "note": "zsc_hip_compress_sections_device, streams resident in HBM, rounds + host "
+                                 "simulation included, this rank only"}
+        del d_sec
+
     if rank == 0:
         total_in = sum(all_lens)
         total_out = sum(all_sizes)
@@ -252,6 +283,8 @@ def main() -> None:
             pass
         if inflate_info:
             line["inflate"] = inflate_info
+        if sections_info:
+            line["sections"] = sections_info
         if not args.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline(args.level)
         print(json.dumps(line), flush=True)

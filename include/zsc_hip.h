@@ -72,6 +72,17 @@ ZlibReturn zsc_hip_compress_sections_batch(U32 count, const U8 *const *sources,
                                            I32 level, I32 window_bits, I32 mem_level,
                                            ZlibStrategy strategy, U32 gzip_header_len);
 
+/* The same with the streams in device memory: stream i is source_lens[i] bytes at d_input +
+ * in_offsets[i] (16-byte aligned) and its compressed stream goes to d_output + out_offsets[i],
+ * of which out_caps[i] bytes may be used (the capacity is part of the result: the wrapper hands
+ * it out in slices of max_block_len).  Synchronous: returns when the streams are in place. */
+ZlibReturn zsc_hip_compress_sections_device(U32 count, const void *d_input,
+                                            const uint64_t *in_offsets, const U32 *source_lens,
+                                            const U32 *max_block_lens, void *d_output,
+                                            const uint64_t *out_offsets, const U32 *out_caps,
+                                            U32 *dest_lens, I32 *statuses, I32 level,
+                                            I32 window_bits, I32 mem_level, ZlibStrategy strategy);
+
 /* Decompress `count` independent streams (host memory).  source_lens[i]: in bytes
  * available, out bytes consumed (reference zsc_uncompress2, zsc_pub.h:385). */
 ZlibReturn zsc_hip_uncompress_batch(U32 count, const U8 *const *sources, U32 *source_lens,

@@ -312,6 +312,11 @@ def test_sections_levels_1_to_9(z, oracle):
             want = oracle.compress(b, lvl, window_bits=wb, mem_level=ml, strategy=strat, max_block_len=m,
                                    dest_cap=cap, work_len=1 << 20)
             assert (s, o) == (want[0], want[1]), (wb, ml, lvl, strat, len(b), m, cap)
+    # items of one section (or none) take the same road and come out like zsc_hip_compress_batch's
+    bufs = [b"", b"a", corpus.make_buffer("text", 70000, 3), corpus.make_buffer("table", 20000, 4)]
+    rc, outs, stats = z.compress_sections_batch(bufs, [1, 5, 70000, 1 << 30], 6)
+    assert rc == 0 and stats == [0, 0, 0, 0]
+    assert outs == z.compress_batch(bufs, 6)[1]
     # a caller's gzip header in front of a stream of sections
     data = corpus.make_buffer("text", 90000, 5)
     h, keep = z.gz_header_for_writing(name=b"sections.txt", comment=b"c" * 300, hcrc=1, time=7)

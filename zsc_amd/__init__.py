@@ -17,6 +17,6 @@ from .api import (  # noqa: F401
     compress_get_min_work_buf_size, compress_get_max_output_size, compress_get_max_output_size2,
     uncompress_get_min_work_buf_size,
     compress, compress2, compress_gzip, uncompress, uncompress2, uncompress_gzip,
-    compress_batch, compress_sections_batch, uncompress_batch, DeflatePlan, InflatePlan,
+    compress_batch, compress_sections_batch, compress_sections_device, uncompress_batch, DeflatePlan, InflatePlan,
     GzHeader, gz_header_for_writing, gz_header_for_reading, gz_header_fields,
 )

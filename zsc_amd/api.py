@@ -66,6 +66,9 @@ def _load() -> C.CDLL:
     L.zsc_hip_compress_sections_batch.argtypes = [C.c_uint32, C.POINTER(C.c_char_p), u32p, u32p,
                                                   C.POINTER(C.c_void_p), u32p, i32p, C.c_int32,
                                                   C.c_int32, C.c_int32, C.c_int32, C.c_uint32]
+    L.zsc_hip_compress_sections_device.argtypes = [C.c_uint32, C.c_void_p, u64p, u32p, u32p, C.c_void_p,
+                                                   u64p, u32p, u32p, i32p, C.c_int32, C.c_int32,
+                                                   C.c_int32, C.c_int32]
     L.zsc_hip_uncompress_batch.argtypes = [C.c_uint32, C.POINTER(C.c_char_p), u32p,
                                            C.POINTER(C.c_void_p), u32p, i32p, C.c_int32]
     L.zsc_hip_inflate_plan_create.argtypes = [C.POINTER(C.c_void_p), C.c_uint32, u32p, u64p, u32p,
@@ -284,6 +287,26 @@ def compress_sections_batch(sources: Sequence[bytes], max_block_lens: Sequence[i
                                              window_bits, mem_level, strategy, 0)
     outs = [bufs[i].raw[:dlen[i]] for i in range(count)] if rc == Z_OK else []
     return rc, outs, list(stat)
+
+
+def compress_sections_device(d_input: int, in_offsets: Sequence[int], source_lens: Sequence[int],
+                             max_block_lens: Sequence[int], d_output: int, out_offsets: Sequence[int],
+                             out_caps: Sequence[int], level: int = 6, window_bits: int = DEF_WBITS,
+                             mem_level: int = DEF_MEM_LEVEL,
+                             strategy: int = Z_DEFAULT_STRATEGY) -> Tuple[int, List[int], List[int]]:
+    """zsc_hip_compress_sections_device: streams and results stay in device memory
+    (d_input / d_output are device pointers).  Returns (rc, stream lengths, statuses)."""
+    count = len(source_lens)
+    ioff = (C.c_uint64 * count)(*in_offsets)
+    slen = (C.c_uint32 * count)(*source_lens)
+    mbls = (C.c_uint32 * count)(*max_block_lens)
+    ooff = (C.c_uint64 * count)(*out_offsets)
+    caps = (C.c_uint32 * count)(*out_caps)
+    dlen = (C.c_uint32 * count)()
+    stat = (C.c_int32 * count)()
+    rc = lib.zsc_hip_compress_sections_device(count, d_input, ioff, slen, mbls, d_output, ooff, caps,
+                                              dlen, stat, level, window_bits, mem_level, strategy)
+    return rc, list(dlen), list(stat)
 
 
 def uncompress_batch(sources: Sequence[bytes], dest_caps: Sequence[int],

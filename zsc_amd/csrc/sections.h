@@ -329,6 +329,13 @@ static inline bool sec_seg_ok(const SecRun &r)
 #define SEC_SPECULATE_BELOW 65537u
 static inline void sec_first_runs(SecStream &s, uint32_t stream_index, std::vector<SecRun *> &jobs)
 {
+    if (s.source_len == 0) { /* an empty stream is one empty run */
+        SecRun &slot = s.runs[0];
+        slot = SecRun();
+        slot.stream = stream_index;
+        jobs.push_back(&slot);
+        return;
+    }
     for (uint32_t a = 0; a < s.source_len; a += s.max_block_len) {
         SecRun r;
         r.stream = stream_index;

@@ -101,45 +101,44 @@ __global__ __launch_bounds__(256) void k_store(const uint8_t *__restrict__ in,
             o[0] = in[pc.src_off] & (uint8_t)pc.arg;
             if (pc.len > 1u)
                 o[1] = 0;
+            return;
         }
+        /* the small pieces; sections.h: only the first pc.len bytes when dest ends inside one */
+        uint8_t t[10];
+        uint32_t nt = 0;
         if (pc.kind == 5u) { /* LEN = 0, NLEN = ~0 of Z_FULL_FLUSH's empty stored block */
-            o[0] = 0;
-            o[1] = 0;
-            o[2] = 0xff;
-            o[3] = 0xff;
-        }
-        if (pc.kind == 1u) { /* Z_FULL_FLUSH's empty stored block, src/deflate.c:1240-1243 */
-            o[0] = 0;
-            o[1] = 0;
-            o[2] = 0;
-            o[3] = 0xff;
-            o[4] = 0xff;
+            t[0] = 0, t[1] = 0, t[2] = 0xff, t[3] = 0xff;
+            nt = 4;
+        } else if (pc.kind == 1u) { /* Z_FULL_FLUSH's empty stored block, src/deflate.c:1240-1243 */
+            t[0] = 0, t[1] = 0, t[2] = 0, t[3] = 0xff, t[4] = 0xff;
+            nt = 5;
         } else if (pc.kind == 2u) {
             if (bufs[pc.buf].wrap == 1u) { /* src/deflate.c:1031-1049 */
-                o[0] = (uint8_t)(pc.arg >> 8);
-                o[1] = (uint8_t)pc.arg;
+                t[0] = (uint8_t)(pc.arg >> 8), t[1] = (uint8_t)pc.arg;
+                nt = 2;
             } else { /* :1068-1082 */
-                o[0] = 31;
-                o[1] = 139;
-                o[2] = 8;
-                o[3] = o[4] = o[5] = o[6] = o[7] = 0;
-                o[8] = (uint8_t)pc.arg;
-                o[9] = 3;
+                t[0] = 31, t[1] = 139, t[2] = 8;
+                t[3] = t[4] = t[5] = t[6] = t[7] = 0;
+                t[8] = (uint8_t)pc.arg, t[9] = 3;
+                nt = 10;
             }
         } else if (pc.kind == 3u) {
             const uint32_t c = res[pc.buf].adler, n = bufs[pc.buf].in_len;
             if (bufs[pc.buf].wrap == 1u) { /* :1282-1286 */
-                o[0] = (uint8_t)(c >> 24);
-                o[1] = (uint8_t)(c >> 16);
-                o[2] = (uint8_t)(c >> 8);
-                o[3] = (uint8_t)c;
+                t[0] = (uint8_t)(c >> 24), t[1] = (uint8_t)(c >> 16), t[2] = (uint8_t)(c >> 8), t[3] = (uint8_t)c;
+                nt = 4;
             } else { /* :1272-1281 */
                 for (uint32_t k = 0; k < 4; k++) {
-                    o[k] = (uint8_t)(c >> (8 * k));
-                    o[4 + k] = (uint8_t)(n >> (8 * k));
+                    t[k] = (uint8_t)(c >> (8 * k));
+                    t[4 + k] = (uint8_t)(n >> (8 * k));
                 }
+                nt = 8;
             }
         }
+        if (pc.len != 0u && pc.len < nt)
+            nt = pc.len;
+        for (uint32_t k = 0; k < nt; k++)
+            o[k] = t[k];
     }
 }
 
@@ -1534,29 +1533,64 @@ struct HipSecRunner {
             out_bytes += ((uint64_t)caps[j] + 16u + 15u) & ~15ull;
         }
         out_bytes += 64;
-        PlanRuns pr = {more.data(), n0.data(), soff.data(), scnt.data(), segok.data(), sched.data(), (uint32_t)sched.size()};
-        zsc_hip_deflate_plan *pl = nullptr;
-        rc = plan_create(&pl, count, lens.data(), in_off.data(), out_off.data(), caps.data(), level,
-                         -wbits, mem_level, strategy, &pr);
-        if (rc != Z_OK)
-            return error = rc;
         Round *rd = new Round();
         rounds.resize(round + 1, nullptr);
         rounds[round] = rd;
         rd->out_off = out_off;
+        if (!rd->d_out.ensure(out_bytes))
+            return error = Z_MEM_ERROR;
+
+        /* the scratch arrays of a plan are ~16 bytes per input byte: groups of jobs, one plan each,
+         * all writing into the round's output */
+        uint64_t group_limit = 2048ull << 20;
+        if (const char *e = getenv("ZSC_HIP_SECTIONS_GROUP_MB"))
+            group_limit = std::max<uint64_t>(1, (uint64_t)atoll(e)) << 20;
+        for (U32 g0 = 0; g0 < count && rc == Z_OK;) {
+            U32 g1 = g0;
+            uint64_t bytes = 0;
+            while (g1 < count && (g1 == g0 || bytes + lens[g1] <= group_limit))
+                bytes += lens[g1++];
+            rc = run_group(jobs, round, g0, g1, lens, caps, more, n0, soff, scnt, segok, sched, out_off, rd);
+            g0 = g1;
+        }
+        parses += count;
+        return error = rc;
+    }
+
+    /* jobs [g0, g1) of a round: gather their input, run the kernels, read the block records back */
+    ZlibReturn run_group(std::vector<SecRun *> &jobs, uint32_t round, U32 g0, U32 g1,
+                         const std::vector<U32> &lens, const std::vector<U32> &caps,
+                         const std::vector<U32> &more, const std::vector<U32> &n0,
+                         const std::vector<U32> &soff, const std::vector<U32> &scnt,
+                         const std::vector<U32> &segok, const std::vector<ZdSched> &sched,
+                         const std::vector<uint64_t> &out_off, Round *rd)
+    {
+        const U32 count = g1 - g0;
+        std::vector<uint64_t> in_off(count);
+        uint64_t in_bytes = 0;
+        for (U32 j = 0; j < count; j++) {
+            in_off[j] = in_bytes;
+            in_bytes += ((uint64_t)lens[g0 + j] + 15u) & ~15ull;
+        }
+        in_bytes += 64;
+        PlanRuns pr = {more.data() + g0, n0.data() + g0, soff.data() + g0, scnt.data() + g0, segok.data() + g0,
+                       sched.data(), (uint32_t)sched.size()};
+        zsc_hip_deflate_plan *pl = nullptr;
+        ZlibReturn rc = plan_create(&pl, count, lens.data() + g0, in_off.data(), out_off.data() + g0,
+                                    caps.data() + g0, level, -wbits, mem_level, strategy, &pr);
+        if (rc != Z_OK)
+            return rc;
         DevBuf d_pieces;
         std::vector<ZdStorePiece> gather(count);
         for (U32 j = 0; j < count; j++) {
             ZdStorePiece &pc = gather[j];
             memset(&pc, 0, sizeof pc);
-            pc.src_off = src_off[jobs[j]->stream] + jobs[j]->start;
+            pc.src_off = src_off[jobs[g0 + j]->stream] + jobs[g0 + j]->start;
             pc.dst_off = in_off[j];
-            pc.len = lens[j];
+            pc.len = lens[g0 + j];
             pc.kind = 6u;
         }
-        rc = Z_OK;
-        if (!rd->d_in.ensure(in_bytes) || !rd->d_out.ensure(out_bytes) ||
-            !d_pieces.ensure(sizeof(ZdStorePiece) * count))
+        if (!rd->d_in.ensure(in_bytes) || !d_pieces.ensure(sizeof(ZdStorePiece) * count))
             rc = Z_MEM_ERROR;
         if (rc == Z_OK && hipMemcpy(d_pieces.p, gather.data(), sizeof(ZdStorePiece) * count,
                                     hipMemcpyHostToDevice) != hipSuccess)
@@ -1585,7 +1619,7 @@ struct HipSecRunner {
              hipMemcpy(res.data(), pl->d_res.p, sizeof(ZdResult) * count, hipMemcpyDeviceToHost) != hipSuccess))
             rc = Z_STREAM_ERROR;
         for (U32 j = 0; j < count && rc == Z_OK; j++) {
-            SecRun &r = *jobs[j];
+            SecRun &r = *jobs[g0 + j];
             const ZdBuf &b = pl->bufs[j];
             if (stat[j] != Z_OK || pout[j].nblocks > b.max_blocks) {
                 ZSC_WARN2("zsc_hip: a run of sections came back with status %d (%u blocks).",
@@ -1605,31 +1639,25 @@ struct HipSecRunner {
                 r.blocks.push_back(blk);
             }
             r.round = round;
-            r.job = j;
+            r.job = g0 + j;
         }
-        parses += count;
         d_pieces.release();
         rd->d_in.release(); /* only the compressed bytes are needed later */
         zsc_hip_deflate_plan_destroy(pl);
-        return error = rc;
+        return rc;
     }
 };
 
 } // namespace
 
-extern "C" ZlibReturn zsc_hip_compress_sections_batch(U32 count, const U8 *const *sources,
-                                                      const U32 *source_lens, const U32 *max_block_lens,
-                                                      U8 *const *dests, U32 *dest_lens, I32 *statuses,
-                                                      I32 level, I32 window_bits, I32 mem_level,
-                                                      ZlibStrategy strategy, U32 gzip_header_len)
+/* the streams are in device memory, stream i at d_src + src_off[i] (16-byte aligned); the finished
+ * streams go to d_dst + dst_off[i], of which dest_caps[i] bytes may be used */
+static ZlibReturn sections_on_device(U32 count, const uint8_t *d_src, const uint64_t *src_off,
+                                     const U32 *source_lens, const U32 *max_block_lens,
+                                     uint8_t *d_dst, const uint64_t *dst_off, const U32 *dest_caps,
+                                     U32 *dest_lens, I32 *statuses, I32 level, I32 window_bits,
+                                     I32 mem_level, ZlibStrategy strategy, U32 gzip_header_len)
 {
-    ZSC_ASSERT(sources != Z_NULL);
-    ZSC_ASSERT(source_lens != Z_NULL);
-    ZSC_ASSERT(max_block_lens != Z_NULL);
-    ZSC_ASSERT(dests != Z_NULL);
-    ZSC_ASSERT(dest_lens != Z_NULL);
-    if (count == 0)
-        return Z_OK;
     if (zsc_hip_init(-1) != Z_OK)
         return Z_STREAM_ERROR;
     int wrap = 1, wbits = 15;
@@ -1651,39 +1679,33 @@ extern "C" ZlibReturn zsc_hip_compress_sections_batch(U32 count, const U8 *const
 
     std::vector<SecStream> streams(count);
     std::vector<ZdBuf> sbufs(count);
-    std::vector<uint64_t> src_off(count);
-    uint64_t in_bytes = 0;
     for (U32 i = 0; i < count; i++) {
         ZSC_ASSERT(max_block_lens[i] != 0);
-        ZSC_ASSERT(sources[i] != Z_NULL);
+        if (src_off[i] & 15u) {
+            ZSC_WARN1("zsc_hip: stream %u is not 16-byte aligned in the batch.", i);
+            return Z_STREAM_ERROR;
+        }
         SecStream &s = streams[i];
         s.source_len = source_lens[i];
         s.max_block_len = max_block_lens[i];
-        s.dest_cap = dest_lens[i];
+        s.dest_cap = dest_caps[i];
         s.wrap = wrap;
         s.hdr_len = wrap == 1 ? 2u : wrap == 2 ? (gzip_header_len ? gzip_header_len : 10u) : 0u;
-        src_off[i] = in_bytes;
         memset(&sbufs[i], 0, sizeof(ZdBuf));
-        sbufs[i].in_off = in_bytes;
+        sbufs[i].in_off = src_off[i];
         sbufs[i].in_len = source_lens[i];
         sbufs[i].wrap = (uint32_t)wrap;
-        in_bytes += ((uint64_t)source_lens[i] + 15u) & ~15ull;
     }
-    DevBuf d_src, d_sbufs, d_sres, d_final, d_pieces;
+    DevBuf d_sbufs, d_sres, d_pieces;
     ZlibReturn rc = Z_OK;
-    if (!d_src.ensure(in_bytes + 64) || !d_sbufs.ensure(sizeof(ZdBuf) * count) ||
-        !d_sres.ensure(sizeof(ZdResult) * count))
+    if (!d_sbufs.ensure(sizeof(ZdBuf) * count) || !d_sres.ensure(sizeof(ZdResult) * count))
         rc = Z_MEM_ERROR;
-    for (U32 i = 0; i < count && rc == Z_OK; i++)
-        if (source_lens[i] && hipMemcpy((uint8_t *)d_src.p + src_off[i], sources[i], source_lens[i],
-                                        hipMemcpyHostToDevice) != hipSuccess)
-            rc = Z_STREAM_ERROR;
     if (rc == Z_OK && hipMemcpy(d_sbufs.p, sbufs.data(), sizeof(ZdBuf) * count, hipMemcpyHostToDevice) != hipSuccess)
         rc = Z_STREAM_ERROR;
 
     HipSecRunner runner;
-    runner.d_src = (const uint8_t *)d_src.p;
-    runner.src_off = src_off.data();
+    runner.d_src = d_src;
+    runner.src_off = src_off;
     runner.level = level;
     runner.mem_level = mem_level;
     runner.wbits = wbits;
@@ -1696,12 +1718,6 @@ extern "C" ZlibReturn zsc_hip_compress_sections_batch(U32 count, const U8 *const
 
     /* put the streams together: per round one launch that copies the runs' bytes, one for the
      * headers / markers / trailers */
-    std::vector<uint64_t> fin_off(count);
-    uint64_t fin_bytes = 0;
-    for (U32 i = 0; i < count; i++) {
-        fin_off[i] = fin_bytes;
-        fin_bytes += ((uint64_t)streams[i].produced + 15u) & ~15ull;
-    }
     std::vector<std::vector<ZdStorePiece>> by_round(runner.rounds.size());
     std::vector<ZdStorePiece> small;
     for (U32 i = 0; i < count && rc == Z_OK; i++) {
@@ -1711,10 +1727,12 @@ extern "C" ZlibReturn zsc_hip_compress_sections_batch(U32 count, const U8 *const
             break;
         }
         for (const SecPiece &sp : streams[i].pieces) {
+            if (sp.dst >= streams[i].delivered)
+                continue; /* behind what the caller gets (dest too small) */
             ZdStorePiece pc;
             memset(&pc, 0, sizeof pc);
-            pc.dst_off = fin_off[i] + sp.dst;
-            pc.len = sp.len;
+            pc.dst_off = dst_off[i] + sp.dst;
+            pc.len = std::min(sp.len, streams[i].delivered - sp.dst);
             pc.buf = i;
             if (sp.kind == SEC_PIECE_RUN || sp.kind == SEC_PIECE_TAIL) {
                 pc.kind = sp.kind == SEC_PIECE_RUN ? 6u : 7u;
@@ -1723,6 +1741,7 @@ extern "C" ZlibReturn zsc_hip_compress_sections_batch(U32 count, const U8 *const
                 by_round[sp.round].push_back(pc);
                 continue;
             }
+            /* a header / marker / trailer: k_store writes the first pc.len bytes of it */
             if (sp.kind == SEC_PIECE_HEADER) {
                 pc.kind = wrap == 2 && gzip_header_len ? 4u : 2u; /* 4: zsc_api.c writes the caller's header */
                 pc.arg = wrap == 1 ? zh : xfl;
@@ -1735,10 +1754,10 @@ extern "C" ZlibReturn zsc_hip_compress_sections_batch(U32 count, const U8 *const
     size_t most = small.size();
     for (const std::vector<ZdStorePiece> &v : by_round)
         most = std::max(most, v.size());
-    if (rc == Z_OK && (!d_final.ensure(fin_bytes + 64) || !d_pieces.ensure(sizeof(ZdStorePiece) * std::max<size_t>(1, most))))
+    if (rc == Z_OK && !d_pieces.ensure(sizeof(ZdStorePiece) * std::max<size_t>(1, most)))
         rc = Z_MEM_ERROR;
     if (rc == Z_OK)
-        hipLaunchKernelGGL(k_checksum, dim3(count), dim3(64), 0, nullptr, (const uint8_t *)d_src.p,
+        hipLaunchKernelGGL(k_checksum, dim3(count), dim3(64), 0, nullptr, d_src,
                            (const ZdBuf *)d_sbufs.p, (ZdResult *)d_sres.p, count);
     for (size_t r = 0; r <= by_round.size() && rc == Z_OK; r++) {
         const std::vector<ZdStorePiece> &v = r < by_round.size() ? by_round[r] : small;
@@ -1748,27 +1767,99 @@ extern "C" ZlibReturn zsc_hip_compress_sections_batch(U32 count, const U8 *const
             rc = Z_STREAM_ERROR;
             break;
         }
-        const uint8_t *from = r < by_round.size() ? (const uint8_t *)runner.rounds[r]->d_out.p : (const uint8_t *)d_src.p;
-        hipLaunchKernelGGL(k_store, dim3((uint32_t)v.size()), dim3(256), 0, nullptr, from,
-                           (uint8_t *)d_final.p, (const ZdStorePiece *)d_pieces.p,
-                           (const ZdBuf *)d_sbufs.p, (const ZdResult *)d_sres.p, (uint32_t)v.size());
+        const uint8_t *from = r < by_round.size() ? (const uint8_t *)runner.rounds[r]->d_out.p : d_src;
+        hipLaunchKernelGGL(k_store, dim3((uint32_t)v.size()), dim3(256), 0, nullptr, from, d_dst,
+                           (const ZdStorePiece *)d_pieces.p, (const ZdBuf *)d_sbufs.p,
+                           (const ZdResult *)d_sres.p, (uint32_t)v.size());
         if (hipDeviceSynchronize() != hipSuccess || hipGetLastError() != hipSuccess)
             rc = Z_STREAM_ERROR; /* d_pieces is reused by the next launch */
     }
     for (U32 i = 0; i < count && rc == Z_OK; i++) {
-        ZSC_ASSERT(dests[i] != Z_NULL);
-        const U32 give = streams[i].delivered;
-        if (give && hipMemcpy(dests[i], (uint8_t *)d_final.p + fin_off[i], give, hipMemcpyDeviceToHost) != hipSuccess)
-            rc = Z_STREAM_ERROR;
-        dest_lens[i] = give;
+        dest_lens[i] = streams[i].delivered;
         if (statuses)
             statuses[i] = (I32)streams[i].status;
     }
-    d_src.release();
     d_sbufs.release();
     d_sres.release();
-    d_final.release();
     d_pieces.release();
+    return rc;
+}
+
+extern "C" ZlibReturn zsc_hip_compress_sections_device(U32 count, const void *d_input,
+                                                       const uint64_t *in_offsets, const U32 *source_lens,
+                                                       const U32 *max_block_lens, void *d_output,
+                                                       const uint64_t *out_offsets, const U32 *out_caps,
+                                                       U32 *dest_lens, I32 *statuses, I32 level,
+                                                       I32 window_bits, I32 mem_level, ZlibStrategy strategy)
+{
+    ZSC_ASSERT(d_input != Z_NULL);
+    ZSC_ASSERT(in_offsets != Z_NULL);
+    ZSC_ASSERT(source_lens != Z_NULL);
+    ZSC_ASSERT(max_block_lens != Z_NULL);
+    ZSC_ASSERT(d_output != Z_NULL);
+    ZSC_ASSERT(out_offsets != Z_NULL);
+    ZSC_ASSERT(out_caps != Z_NULL);
+    ZSC_ASSERT(dest_lens != Z_NULL);
+    if (count == 0)
+        return Z_OK;
+    return sections_on_device(count, (const uint8_t *)d_input, in_offsets, source_lens, max_block_lens,
+                              (uint8_t *)d_output, out_offsets, out_caps, dest_lens, statuses, level,
+                              window_bits, mem_level, strategy, 0);
+}
+
+extern "C" ZlibReturn zsc_hip_compress_sections_batch(U32 count, const U8 *const *sources,
+                                                      const U32 *source_lens, const U32 *max_block_lens,
+                                                      U8 *const *dests, U32 *dest_lens, I32 *statuses,
+                                                      I32 level, I32 window_bits, I32 mem_level,
+                                                      ZlibStrategy strategy, U32 gzip_header_len)
+{
+    ZSC_ASSERT(sources != Z_NULL);
+    ZSC_ASSERT(source_lens != Z_NULL);
+    ZSC_ASSERT(max_block_lens != Z_NULL);
+    ZSC_ASSERT(dests != Z_NULL);
+    ZSC_ASSERT(dest_lens != Z_NULL);
+    if (count == 0)
+        return Z_OK;
+    if (zsc_hip_init(-1) != Z_OK)
+        return Z_STREAM_ERROR;
+    std::vector<uint64_t> src_off(count), dst_off(count);
+    std::vector<U32> caps(count), got(count);
+    uint64_t in_bytes = 0, out_bytes = 0;
+    for (U32 i = 0; i < count; i++) {
+        ZSC_ASSERT(sources[i] != Z_NULL);
+        ZSC_ASSERT(dests[i] != Z_NULL);
+        src_off[i] = in_bytes;
+        dst_off[i] = out_bytes;
+        caps[i] = dest_lens[i];
+        in_bytes += ((uint64_t)source_lens[i] + 15u) & ~15ull;
+        /* a stream never grows past its bound by much, whatever dest the caller has */
+        U32 bound = 0;
+        if (zsc_compress_get_max_output_size2(source_lens[i], max_block_lens[i], level, window_bits,
+                                              mem_level, &bound) != Z_OK)
+            bound = dest_lens[i];
+        const uint64_t room = std::min<uint64_t>(dest_lens[i], (uint64_t)bound + gzip_header_len +
+                                                                   source_lens[i] / max_block_lens[i] * 8ull + 4096u);
+        out_bytes += (room + 15u) & ~15ull;
+    }
+    DevBuf d_src, d_dst;
+    ZlibReturn rc = Z_OK;
+    if (!d_src.ensure(in_bytes + 64) || !d_dst.ensure(out_bytes + 64))
+        rc = Z_MEM_ERROR;
+    for (U32 i = 0; i < count && rc == Z_OK; i++)
+        if (source_lens[i] && hipMemcpy((uint8_t *)d_src.p + src_off[i], sources[i], source_lens[i],
+                                        hipMemcpyHostToDevice) != hipSuccess)
+            rc = Z_STREAM_ERROR;
+    if (rc == Z_OK)
+        rc = sections_on_device(count, (const uint8_t *)d_src.p, src_off.data(), source_lens, max_block_lens,
+                                (uint8_t *)d_dst.p, dst_off.data(), caps.data(), got.data(), statuses, level,
+                                window_bits, mem_level, strategy, gzip_header_len);
+    for (U32 i = 0; i < count && rc == Z_OK; i++) {
+        if (got[i] && hipMemcpy(dests[i], (uint8_t *)d_dst.p + dst_off[i], got[i], hipMemcpyDeviceToHost) != hipSuccess)
+            rc = Z_STREAM_ERROR;
+        dest_lens[i] = got[i];
+    }
+    d_src.release();
+    d_dst.release();
     return rc;
 }
 
