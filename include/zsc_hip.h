@@ -32,9 +32,10 @@ I32 zsc_hip_init(I32 device_ordinal);
 /* human readable "device name | arch | CUs", valid until the next call */
 const char *zsc_hip_device_info(void);
 
-/* Device memory of finished calls and destroyed plans is kept (at most 4 GiB) for the next
- * ones, which saves the one-shot entry points most of their hipMalloc/hipFree time; this
- * gives it back.  ZSC_HIP_NO_CACHE=1 in the environment keeps nothing. */
+/* Device memory of finished calls and destroyed plans is kept for the next ones (at most a
+ * quarter of the device's memory, or ZSC_HIP_CACHE_MB from the environment), which saves the
+ * one-shot entry points their hipMalloc/hipFree time -- unmapping the scratch arrays was two
+ * thirds of a sections call; this gives it back.  ZSC_HIP_NO_CACHE=1 keeps nothing. */
 void zsc_hip_release_cached_memory(void);
 
 /* host-pointer batches ---------------------------------------------------- */

@@ -13,6 +13,7 @@
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
+#include <chrono>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
@@ -458,6 +459,15 @@ __global__ __launch_bounds__(64) void k_layout(const ZdBuf *__restrict__ bufs,
                   out + bufs[b].out_off);
 }
 
+/* sections.h wants to know where every block ends: the bit_off column of the plans, packed */
+__global__ __launch_bounds__(256) void k_bit_offs(const ZdBlockPlan *__restrict__ plans,
+                                                  uint32_t *__restrict__ out, uint32_t nslots)
+{
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < nslots)
+        out[i] = plans[i].bit_off;
+}
+
 /* kernel 4b: one wavefront per block */
 __global__ __launch_bounds__(64) void k_emit(const uint8_t *__restrict__ in,
                                              const ZdBuf *__restrict__ bufs,
@@ -540,6 +550,8 @@ char g_device_info[256] = "uninitialised";
         }                                                                                \
     } while (0)
 
+size_t g_dev_cache_cap = 4ull << 30; /* DevCache: bytes of freed device memory kept at most */
+
 void do_init(int ordinal)
 {
     int count = 0;
@@ -570,16 +582,20 @@ void do_init(int ordinal)
         g_init_status = Z_STREAM_ERROR;
         return;
     }
+    g_dev_cache_cap = prop.totalGlobalMem / 4;
+    if (const char *e = getenv("ZSC_HIP_CACHE_MB"))
+        g_dev_cache_cap = (size_t)atoll(e) << 20;
     g_init_status = Z_OK;
 }
 
 /* Freed device blocks, kept for the next plan.  The one-shot entry points (zsc_compress ...)
  * build and drop a plan per call and the sections path one per round; hipMalloc / hipFree cost
- * a tenth of a millisecond each and hipFree waits for the device.  At most kMaxHeld bytes in
- * kMaxBlocks blocks are kept (ZSC_HIP_NO_CACHE: none); a block serves a request of at least
- * half its size. */
+ * a tenth of a millisecond each, hipFree waits for the device and takes ~30 ms per GB it
+ * unmaps -- with ~16 B of scratch per input byte that was two thirds of a sections call.  At
+ * most g_dev_cache_cap bytes (a quarter of the device's memory; ZSC_HIP_CACHE_MB) in kMaxBlocks blocks
+ * are kept (ZSC_HIP_NO_CACHE: none); a block serves a request of at least half its size. */
 struct DevCache {
-    static constexpr size_t kMaxHeld = 4ull << 30, kMaxBlocks = 96;
+    static constexpr size_t kMaxBlocks = 96;
     std::mutex mu;
     std::vector<std::pair<size_t, void *>> blocks;
     size_t held = 0;
@@ -605,7 +621,7 @@ struct DevCache {
     bool give(void *p, size_t bytes)
     {
         std::lock_guard<std::mutex> lock(mu);
-        if (off || blocks.size() >= kMaxBlocks || held + bytes > kMaxHeld)
+        if (off || blocks.size() >= kMaxBlocks || held + bytes > g_dev_cache_cap)
             return false;
         blocks.push_back(std::make_pair(bytes, p));
         held += bytes;
@@ -1505,6 +1521,7 @@ struct HipSecRunner {
 
     int operator()(std::vector<SecRun *> &jobs, uint32_t round)
     {
+        const auto t_begin = std::chrono::steady_clock::now();
         const U32 count = (U32)jobs.size();
         std::vector<U32> lens(count), caps(count), more(count), n0(count), soff(count), scnt(count), segok(count);
         std::vector<uint64_t> in_off(count), out_off(count);
@@ -1554,6 +1571,14 @@ struct HipSecRunner {
             g0 = g1;
         }
         parses += count;
+        if (getenv("ZSC_HIP_SECTIONS_LOG")) {
+            uint64_t bytes = 0, joints = 0;
+            for (U32 j = 0; j < count; j++)
+                bytes += lens[j], joints += scnt[j];
+            const double ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_begin).count();
+            fprintf(stderr, "zsc_hip sections: round %u: %u runs, %llu bytes, %llu joints, %.2f ms\n", round, count,
+                    (unsigned long long)bytes, (unsigned long long)joints, ms);
+        }
         return error = rc;
     }
 
@@ -1611,10 +1636,15 @@ struct HipSecRunner {
         std::vector<uint32_t> bit_off(sb.nslots);
         std::vector<ZdParseOut> pout(count);
         std::vector<ZdResult> res(count);
+        DevBuf d_bits;
+        if (rc == Z_OK && !d_bits.ensure(4ull * std::max(1u, sb.nslots)))
+            rc = Z_MEM_ERROR;
+        if (rc == Z_OK && sb.nslots)
+            hipLaunchKernelGGL(k_bit_offs, dim3((sb.nslots + 255) / 256), dim3(256), 0, nullptr,
+                               (const ZdBlockPlan *)pl->d_plans.p, (uint32_t *)d_bits.p, sb.nslots);
         if (rc == Z_OK &&
             (hipMemcpy(recs.data(), pl->d_recs.p, sizeof(ZdBlockRec) * sb.nslots, hipMemcpyDeviceToHost) != hipSuccess ||
-             hipMemcpy2D(bit_off.data(), 4, (const uint8_t *)pl->d_plans.p + offsetof(ZdBlockPlan, bit_off),
-                         sizeof(ZdBlockPlan), 4, sb.nslots, hipMemcpyDeviceToHost) != hipSuccess ||
+             hipMemcpy(bit_off.data(), d_bits.p, 4ull * sb.nslots, hipMemcpyDeviceToHost) != hipSuccess ||
              hipMemcpy(pout.data(), pl->d_pout.p, sizeof(ZdParseOut) * count, hipMemcpyDeviceToHost) != hipSuccess ||
              hipMemcpy(res.data(), pl->d_res.p, sizeof(ZdResult) * count, hipMemcpyDeviceToHost) != hipSuccess))
             rc = Z_STREAM_ERROR;
@@ -1642,6 +1672,7 @@ struct HipSecRunner {
             r.job = g0 + j;
         }
         d_pieces.release();
+        d_bits.release();
         rd->d_in.release(); /* only the compressed bytes are needed later */
         zsc_hip_deflate_plan_destroy(pl);
         return rc;
@@ -1710,11 +1741,13 @@ static ZlibReturn sections_on_device(U32 count, const uint8_t *d_src, const uint
     runner.mem_level = mem_level;
     runner.wbits = wbits;
     runner.strategy = strategy;
+    const auto t_begin = std::chrono::steady_clock::now();
     if (rc == Z_OK) {
         const int e = sec_compress(streams, runner);
         if (e != 0)
             rc = runner.error != Z_OK ? runner.error : Z_STREAM_ERROR;
     }
+    const auto t_parsed = std::chrono::steady_clock::now();
 
     /* put the streams together: per round one launch that copies the runs' bytes, one for the
      * headers / markers / trailers */
@@ -1778,6 +1811,12 @@ static ZlibReturn sections_on_device(U32 count, const uint8_t *d_src, const uint
         dest_lens[i] = streams[i].delivered;
         if (statuses)
             statuses[i] = (I32)streams[i].status;
+    }
+    if (getenv("ZSC_HIP_SECTIONS_LOG")) {
+        const auto t_end = std::chrono::steady_clock::now();
+        fprintf(stderr, "zsc_hip sections: %u streams, rounds + simulation %.2f ms, putting together %.2f ms\n", count,
+                std::chrono::duration<double, std::milli>(t_parsed - t_begin).count(),
+                std::chrono::duration<double, std::milli>(t_end - t_parsed).count());
     }
     d_sbufs.release();
     d_sres.release();
