@@ -93,3 +93,52 @@ def test_gz_header_argument_errors_need_no_gpu():
     hr, bufs = zsc_amd.gz_header_for_reading(4, 4, 4)
     assert zsc_amd.uncompress2(b"\x78\x9c\x03\x00\x00\x00\x00\x01", 10, 15, gz_header=hr)[0] == \
         m["header_on_zlib_uncompress"] == -2
+
+
+def test_null_pointers_die_in_zsc_assert():
+    """The reference's ZlibDeathTest.Asserts (test/zlib_gtest.cpp:2093-2396): a NULL pointer into a
+    zsc_* function is not an error code, it trips ZSC_ASSERT naming the parameter
+    (src/zsc_compress.c:56-59, src/zsc_uncompr.c:48-52); max_block_len == 0 too (:124).
+    Each case in its own process; none of them gets as far as the GPU."""
+    import subprocess
+    import sys
+    import zsc_amd
+    prologue = (
+        "import ctypes as C, sys\n"
+        f"L = C.CDLL({zsc_amd.lib_path!r})\n"
+        "n = C.c_uint32(0); m = C.c_uint32(100); s = C.c_uint32(8)\n"
+        "src = C.create_string_buffer(b'abcdefgh'); dst = C.create_string_buffer(100); work = C.create_string_buffer(400000)\n"
+        "p = C.byref\n")
+    cases = [
+        ("size_out", "L.zsc_compress_get_min_work_buf_size(None)"),
+        ("size_out", "L.zsc_compress_get_min_work_buf_size2(15, 8, None)"),
+        ("size_out", "L.zsc_compress_get_max_output_size(8, 8, 6, None)"),
+        ("size_out", "L.zsc_compress_get_max_output_size2(8, 8, 6, 15, 8, None)"),
+        ("size_out", "L.zsc_compress_get_max_output_size_gzip(8, 8, 6, None, None)"),
+        ("size_out", "L.zsc_compress_get_max_output_size_gzip2(8, 8, 6, 31, 8, None, None)"),
+        ("max_block_len", "L.zsc_compress_get_max_output_size(8, 0, 6, p(n))"),
+        ("size_out", "L.zsc_uncompress_get_min_work_buf_size(None)"),
+        ("size_out", "L.zsc_uncompress_get_min_work_buf_size2(15, None)"),
+        ("dest", "L.zsc_compress(None, p(m), src, 8, 8, work, 400000, 6)"),
+        ("dest_len", "L.zsc_compress(dst, None, src, 8, 8, work, 400000, 6)"),
+        ("source", "L.zsc_compress(dst, p(m), None, 8, 8, work, 400000, 6)"),
+        ("work", "L.zsc_compress(dst, p(m), src, 8, 8, None, 400000, 6)"),
+        ("max_block_len", "L.zsc_compress(dst, p(m), src, 8, 0, work, 400000, 6)"),
+        ("dest", "L.zsc_compress2(None, p(m), src, 8, 8, work, 400000, 6, 15, 8, 0)"),
+        ("source", "L.zsc_compress_gzip(dst, p(m), None, 8, 8, work, 400000, 6, None)"),
+        ("work", "L.zsc_compress_gzip2(dst, p(m), src, 8, 8, None, 400000, 6, 31, 8, 0, None)"),
+        ("dest", "L.zsc_uncompress(None, p(m), src, p(s), work, 400000)"),
+        ("dest_len", "L.zsc_uncompress(dst, None, src, p(s), work, 400000)"),
+        ("source", "L.zsc_uncompress(dst, p(m), None, p(s), work, 400000)"),
+        ("source_len", "L.zsc_uncompress(dst, p(m), src, None, work, 400000)"),
+        ("work", "L.zsc_uncompress(dst, p(m), src, p(s), None, 400000)"),
+        ("dest", "L.zsc_uncompress2(None, p(m), src, p(s), work, 400000, 15)"),
+        ("source", "L.zsc_uncompress_gzip(dst, p(m), None, p(s), work, 400000, None)"),
+        ("work", "L.zsc_uncompress_gzip2(dst, p(m), src, p(s), None, 400000, 31, None)"),
+    ]
+    procs = [(name, call, subprocess.Popen([sys.executable, "-c", prologue + call + "\nsys.exit(0)\n"],
+                                           stdout=subprocess.DEVNULL, stderr=subprocess.PIPE))
+             for name, call in cases]
+    for name, call, pr in procs:
+        err = pr.communicate()[1].decode(errors="replace")
+        assert pr.returncode == -6 and "Assertion" in err and name in err, (call, pr.returncode, err[-300:])
