@@ -41,6 +41,8 @@ static inline void sg_count(int what, unsigned n)
 #include "../../zsc_amd/csrc/checksum.h"
 #include "../../zsc_amd/csrc/inflate.h"
 #include "../../zsc_amd/csrc/sections.h"
+#include <cstdio>
+#include <cstdlib>
 
 static const ZdLevel kLevels[10] = {
     {0, 0, 0, 0, 0},       {4, 4, 8, 4, 0},       {4, 5, 16, 8, 0},     {4, 6, 32, 32, 0},
@@ -184,28 +186,32 @@ static void run_parse(const LzJob &job)
         return;
     }
     if (job.cfg.slow) {
-        /* the ring class the runtime would pick for this length */
-        if (job.n > 18432u) {
-            LzLds *lds = (LzLds *)malloc(sizeof(LzLds));
-            memset(lds, 0xA5, sizeof(LzLds));
-            lz_parse_lazy<LzLds>(job, lds);
-            free(lds);
-        } else if (job.n > 10240u) {
-            LzLds16k *lds = (LzLds16k *)malloc(sizeof(LzLds16k));
-            memset(lds, 0xA5, sizeof(LzLds16k));
-            lz_parse_lazy<LzLds16k>(job, lds);
-            free(lds);
-        } else if (job.n > 6144u) {
-            LzLds8k *lds = (LzLds8k *)malloc(sizeof(LzLds8k));
-            memset(lds, 0xA5, sizeof(LzLds8k));
-            lz_parse_lazy<LzLds8k>(job, lds);
-            free(lds);
-        } else {
-            LzLds4k *lds = (LzLds4k *)malloc(sizeof(LzLds4k));
-            memset(lds, 0xA5, sizeof(LzLds4k));
-            lz_parse_lazy<LzLds4k>(job, lds);
-            free(lds);
-        }
+        /* the ring class the runtime would pick for this length; runs with joints keep a hole map */
+#define EMU_LAZY(LT)                                 \
+    do {                                             \
+        LT *lds = (LT *)malloc(sizeof(LT));          \
+        memset(lds, 0xA5, sizeof(LT));               \
+        lz_parse_lazy<LT>(job, lds);                 \
+        free(lds);                                   \
+    } while (0)
+        if (job.nsched) {
+            if (job.n > 18432u)
+                EMU_LAZY(LzLdsJ);
+            else if (job.n > 10240u)
+                EMU_LAZY(LzLdsJ16k);
+            else if (job.n > 6144u)
+                EMU_LAZY(LzLdsJ8k);
+            else
+                EMU_LAZY(LzLdsJ4k);
+        } else if (job.n > 18432u)
+            EMU_LAZY(LzLds);
+        else if (job.n > 10240u)
+            EMU_LAZY(LzLds16k);
+        else if (job.n > 6144u)
+            EMU_LAZY(LzLds8k);
+        else
+            EMU_LAZY(LzLds4k);
+#undef EMU_LAZY
     } else {
         LzLdsFast *lds = (LzLdsFast *)malloc(sizeof(LzLdsFast));
         memset(lds, 0xA5, sizeof(LzLdsFast));
@@ -395,8 +401,11 @@ struct EmuSecRunner {
             job.ntot = r.n;
             g_job_seg_ok = sec_seg_ok(r);
             run_parse(job);
-            if (po.nblocks > max_blocks)
+            if (po.nblocks > max_blocks) {
+                if (getenv("ZSC_EMU_DEBUG"))
+                    fprintf(stderr, "emu: run at %u n %u: %u blocks > %u\n", r.start, r.n, po.nblocks, max_blocks);
                 return -2;
+            }
 
             ZdBuf buf;
             memset(&buf, 0, sizeof buf);
@@ -418,8 +427,11 @@ struct EmuSecRunner {
             std::vector<uint32_t> &outw = outs[round][j];
             outw.assign(((size_t)buf.out_cap + 64) / 4 + 4, 0xCDCDCDCD);
             layout_buffer(&buf, &po, recs.data(), plans.data(), &res, (uint8_t *)outw.data());
-            if (res.status != 0)
+            if (res.status != 0) {
+                if (getenv("ZSC_EMU_DEBUG"))
+                    fprintf(stderr, "emu: run at %u n %u: layout status %d (out_len %u cap %u)\n", r.start, r.n, res.status, res.out_len, buf.out_cap);
                 return res.status;
+            }
             for (uint32_t b = 0; b < po.nblocks; b++) {
                 BeLds bl;
                 memset(&bl, 0x77, sizeof bl);
@@ -464,6 +476,8 @@ extern "C" int emu_compress_sections(const uint8_t *src, uint32_t n, uint32_t ma
     const int rc = sec_compress(streams, runner);
     *parses_out = runner.parses;
     *out_len = 0;
+    if (getenv("ZSC_EMU_DEBUG"))
+        fprintf(stderr, "emu: sec_compress rc %d, stream status %d done %d (sections.h:%d)\n", rc, s.status, (int)s.done, s.broken_line);
     if (rc != 0)
         return rc;
     std::vector<uint8_t> whole((size_t)s.produced + 16, 0xEE);

@@ -200,7 +200,7 @@ def test_sections_rounds_and_joints(emu, oracle):
             mbl = n // 300 + 1
         lvl = rnd.choice([1, 3, 4, 6, 9])
         wb = rnd.choice([15, 15, 31, -15, 12, 9])
-        ml = rnd.choice([8, 8, 8, 9, 5])
+        ml = rnd.choice([8, 8, 8, 9, 5, 1, 2])
         strat = rnd.choice([0, 0, 1, 4, 2, 3]) if ml >= 8 else 0   # the reference asserts on Z_FIXED + small mem_level
         bound = oracle.max_output(n, mbl, lvl, wb, ml)[1]
         cap = rnd.choice([bound, bound, bound + 100, max(1, bound // 2), max(1, bound // 8)])
@@ -210,3 +210,17 @@ def test_sections_rounds_and_joints(emu, oracle):
         assert (rc, out) == (want[0], want[1]), (it, n, mbl, lvl, wb, ml, strat, cap)
         rejoined += parses - (n + mbl - 1) // mbl
     assert rejoined > 150   # runs parsed again: joints are the rule, not the exception (most are speculated)
+    # found by tools/soak.py on the GPU: with mem_level 1 a block fills up (127 symbols) exactly where a
+    # 164-byte section ends; the next section is let in while that block is flushed, so nobody catches up
+    # on the section's last two positions (no s->insert): they never enter the reference's hash chains
+    data = corpus.make_buffer("object", 65535, 978947581)[:26000]
+    bound = oracle.max_output(len(data), 164, 6, 15, 1)[1]
+    want = oracle.compress(data, 6, mem_level=1, max_block_len=164, dest_cap=bound, work_len=1 << 20)
+    assert emu_compress_sections(emu, data, 164, 6, 15, 0, bound, 1)[:2] == (want[0], want[1])
+    for seed in (3, 4):
+        for ml in (1, 2):
+            data = corpus.make_buffer("random", 40000, seed)   # runs that outgrow the small rings
+            bound = oracle.max_output(len(data), 376, 4, -15, ml)[1]
+            want = oracle.compress(data, 4, window_bits=-15, mem_level=ml, max_block_len=376, dest_cap=bound,
+                                   work_len=1 << 20)
+            assert emu_compress_sections(emu, data, 376, 4, -15, 0, bound, ml)[:2] == (want[0], want[1])

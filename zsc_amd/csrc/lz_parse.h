@@ -33,14 +33,18 @@
 
 /* LDS of the lazy parser (levels 4-9): 36 KiB window ring + look-ahead rings = 39 680 B,
  * four waves per CU */
-template <uint32_t RING_BYTES, uint32_t CHUNK_BYTES>
+template <uint32_t RING_BYTES, uint32_t CHUNK_BYTES, bool WITH_HOLES = false>
 struct LzLdsT {
     static constexpr uint32_t RING = RING_BYTES, CHUNK = CHUNK_BYTES;
-    static constexpr bool HAS_INS = false;
+    static constexpr bool HAS_INS = WITH_HOLES; /* lz_load_chunk clears ins[] for what enters the ring */
+    static constexpr bool HOLES = WITH_HOLES;
     uint8_t ring[RING + 512]; /* sliding window; first 16 bytes mirrored after the end, rest slack for masked over-reads */
     uint32_t stage[WAVE];     /* symbols waiting for a coalesced store */
     uint16_t prank[LZ_PR];    /* rank[] of the next few hundred positions */
     uint16_t phib[LZ_PR];     /* hib[] of the same positions */
+    /* WITH_HOLES (runs of sections with joints): bit r = the position at ring index r never
+     * entered the reference's hash chains (lz_parse_lazy, "holes") */
+    uint32_t ins[WITH_HOLES ? RING / 32 : 1];
 };
 typedef LzLdsT<ZD_RING, ZD_CHUNK> LzLds;
 /* a buffer that fits the ring whole never slides it, so short buffers can run with a
@@ -48,6 +52,11 @@ typedef LzLdsT<ZD_RING, ZD_CHUNK> LzLds;
 typedef LzLdsT<18432u, 2048u> LzLds16k; /* n <= 18 432: 7 waves per CU */
 typedef LzLdsT<10240u, 2048u> LzLds8k;  /* n <= 10 240: 12 waves per CU */
 typedef LzLdsT<6144u, 2048u> LzLds4k;   /* n <=  6 144: 17 waves per CU */
+/* the same with the hole map, for runs of sections that have joints */
+typedef LzLdsT<ZD_RING, ZD_CHUNK, true> LzLdsJ;
+typedef LzLdsT<18432u, 2048u, true> LzLdsJ16k;
+typedef LzLdsT<10240u, 2048u, true> LzLdsJ8k;
+typedef LzLdsT<6144u, 2048u, true> LzLdsJ4k;
 
 /* LDS of the greedy parser (levels 1-3): a 34 KiB ring (2 KiB chunks) leaves room for
  * the one-bit-per-position "was inserted" map deflate_fast needs (it does not index the
@@ -55,6 +64,7 @@ typedef LzLdsT<6144u, 2048u> LzLds4k;   /* n <=  6 144: 17 waves per CU */
 struct LzLdsFast {
     static constexpr uint32_t RING = 34816u, CHUNK = 2048u;
     static constexpr bool HAS_INS = true;
+    static constexpr bool HOLES = false;
     uint8_t ring[RING + 512];
     uint32_t stage[WAVE];
     uint32_t ins[RING / 32];  /* bit r: the position at ring index r is in the hash chains */
@@ -123,10 +133,12 @@ DEV void lz_load_chunk(const LzJob &job, L *lds, LzState &st)
     }
     if constexpr (L::HAS_INS) {
         /* positions that enter the ring have not been inserted into any chain yet */
-        FOR_LANES
-        {
-            if ((uint32_t)LANE < L::CHUNK / 32u)
-                lds->ins[r0 / 32u + (uint32_t)LANE] = 0;
+        for (uint32_t k = 0; k < L::CHUNK / 32u; k += WAVE) {
+            FOR_LANES
+            {
+                if (k + (uint32_t)LANE < L::CHUNK / 32u)
+                    lds->ins[r0 / 32u + k + (uint32_t)LANE] = 0;
+            }
         }
     }
     WAVE_SYNC();
@@ -179,8 +191,11 @@ DEV int lz_put(const LzJob &job, L *lds, LzState &st, uint32_t sym)
 }
 
 /* FLUSH_BLOCK_ONLY, reference src/deflate.c:1660-1668 */
-DEV void lz_cut(const LzJob &job, LzState &st, uint32_t upto, uint32_t last, uint32_t cut)
+/* returns the end of the input as it was before, if a joint of kind 0 let the next section in
+ * at this cut; 0xffffffff otherwise */
+DEV uint32_t lz_cut(const LzJob &job, LzState &st, uint32_t upto, uint32_t last, uint32_t cut)
 {
+    uint32_t joint_n = 0xffffffffu;
     ON_LANE0
     {
         ZdBlockRec *b = &job.blocks[st.nblocks];
@@ -201,10 +216,12 @@ DEV void lz_cut(const LzJob &job, LzState &st, uint32_t upto, uint32_t last, uin
     if (cut == ZD_CUT_FULL && st.si < job.nsched) {
         const uint32_t jp = UNI(job.sched[st.si].pos), jk = UNI(job.sched[st.si].kind);
         if (jk == 0u && jp == upto) {
+            joint_n = st.n;
             st.n = UNI(job.sched[st.si].new_n);
             st.si++;
         }
     }
+    return joint_n;
 }
 
 /* the input given so far is used up at p: is there a joint of kind 1 here?  (The caller has
@@ -217,7 +234,7 @@ DEV int lz_joint_at_end(const LzJob &job, LzState &st, uint32_t p)
     if (UNI(job.sched[st.si].kind) != 1u || UNI(job.sched[st.si].pos) != p)
         return 0;
     if (st.nsyms != st.blk_sym0)
-        lz_cut(job, st, p, 0, ZD_CUT_END);
+        (void)lz_cut(job, st, p, 0, ZD_CUT_END);
     st.n = UNI(job.sched[st.si].new_n);
     st.si++;
     return 1;
@@ -228,9 +245,9 @@ DEV int lz_joint_at_end(const LzJob &job, LzState &st, uint32_t p)
 DEV void lz_cut_end(const LzJob &job, LzState &st, uint32_t p)
 {
     if (!job.more)
-        lz_cut(job, st, p, 1, ZD_CUT_END);
+        (void)lz_cut(job, st, p, 1, ZD_CUT_END);
     else if (st.nsyms != st.blk_sym0)
-        lz_cut(job, st, p, 0, ZD_CUT_END);
+        (void)lz_cut(job, st, p, 0, ZD_CUT_END);
 }
 
 /* fill_window's slide decision, reference src/deflate.c:1563-1570,1589 */
@@ -346,9 +363,50 @@ typedef struct {
     int head_seen;
 } LzSearch;
 
+/* Holes (runs of sections with joints, lazy parse).  deflate_slow indexes every position -- but
+ * only once three bytes of lookahead are there (:2018, and max_insert inside a match, :2069-2075).
+ * The last two positions of the input given so far are caught up with by fill_window when the
+ * call ended regularly (s->insert, :2113 + :1591-1612).  When deflate() instead came back from
+ * flushing a full block right there and the next section was let in (a joint of kind 0 at the
+ * very end of the input), nobody catches up: what the parse had already passed of those two
+ * positions never enters the chains.  One bit per ring position remembers them. */
+template <class L>
+DEV int lz_is_hole(const L *lds, const LzState &st, uint32_t q)
+{
+    if constexpr (L::HOLES) {
+        const uint32_t r = lz_ridx<L>(st, q);
+        return (int)((lds->ins[r >> 5] >> (r & 31u)) & 1u);
+    } else {
+        (void)lds;
+        (void)st;
+        (void)q;
+        return 0;
+    }
+}
+
+template <class L>
+DEV void lz_mark_holes(L *lds, const LzState &st, uint32_t old_n, uint32_t p_next)
+{
+    if constexpr (L::HOLES) {
+        for (uint32_t k = 2; k >= 1; k--) {
+            if (old_n >= k && old_n - k < p_next) {
+                const uint32_t r = lz_ridx<L>(st, old_n - k);
+                ON_LANE0 { lds->ins[r >> 5] |= 1u << (r & 31u); }
+            }
+        }
+        WAVE_SYNC();
+    } else {
+        (void)lds;
+        (void)st;
+        (void)old_n;
+        (void)p_next;
+    }
+}
+
 /* chain membership of a candidate: the lazy parser indexes every position
  * (src/deflate.c:2018,2069-2075), the greedy one only those it marked (:1914,1940-1950) */
 #define LZ_MEMB_ALL(q) 1
+#define LZ_MEMB_LAZY(q) (!lz_is_hole<L>(lds, st, (q)))
 #define LZ_MEMB_INS(q) ((lds->ins[lz_ridx<L>(st, (q)) >> 5] >> (lz_ridx<L>(st, (q)) & 31u)) & 1u)
 
 /* Evaluate one batch of 64 sorted entries (ENT, newest first) that lie in the tile
@@ -599,16 +657,16 @@ DEV void lz_parse_lazy(const LzJob &job, L *lds)
             const uint32_t *runA = job.sorted + (uint64_t)tile * ZD_TILE;
             int verdict = 0;
             /* own tile: first batch from the slot, the rest in groups of four */
-            LZ_EVAL_BATCH(cA, tile << 15, LZ_MEMB_ALL, verdict);
+            LZ_EVAL_BATCH(cA, tile << 15, LZ_MEMB_LAZY, verdict);
             if (verdict == 0)
-                LZ_WALK_RUN(runA, (int32_t)UNI(lds->prank[p & (LZ_PR - 1)]) - 1, tile << 15, LZ_MEMB_ALL, verdict);
+                LZ_WALK_RUN(runA, (int32_t)UNI(lds->prank[p & (LZ_PR - 1)]) - 1, tile << 15, LZ_MEMB_LAZY, verdict);
             if (verdict == 1 && tile != 0) {
                 /* older tile */
                 verdict = 0;
-                LZ_EVAL_BATCH(cB, (tile - 1) << 15, LZ_MEMB_ALL, verdict);
+                LZ_EVAL_BATCH(cB, (tile - 1) << 15, LZ_MEMB_LAZY, verdict);
                 if (verdict == 0)
                     LZ_WALK_RUN(runA - ZD_TILE, (int32_t)(int16_t)UNI(lds->phib[p & (LZ_PR - 1)]),
-                                (tile - 1) << 15, LZ_MEMB_ALL, verdict);
+                                (tile - 1) << 15, LZ_MEMB_LAZY, verdict);
             }
             /* verdict 3: the reference would not have called longest_match */
             if (verdict != 3 && sc.head_seen) {
@@ -624,13 +682,19 @@ DEV void lz_parse_lazy(const LzJob &job, L *lds)
             pending = 0;
             cur_len = 2;
             p += prev_len - 1;
-            if (full)
-                lz_cut(job, st, p, 0, ZD_CUT_FULL);
+            if (full) {
+                const uint32_t old_n = lz_cut(job, st, p, 0, ZD_CUT_FULL);
+                if (old_n != 0xffffffffu)
+                    lz_mark_holes<L>(lds, st, old_n, p);
+            }
         } else if (pending) {
             const uint32_t c = UNI(lds->ring[lz_ridx<L>(st, p - 1)]);
+            uint32_t old_n = 0xffffffffu;
             if (lz_put<L>(job, lds, st, c))
-                lz_cut(job, st, p, 0, ZD_CUT_FULL);
+                old_n = lz_cut(job, st, p, 0, ZD_CUT_FULL);
             p++;
+            if (old_n != 0xffffffffu)
+                lz_mark_holes<L>(lds, st, old_n, p);
         } else {
             pending = 1;
             p++;
@@ -752,7 +816,7 @@ DEV void lz_parse_greedy(const LzJob &job, LzLdsFast *lds)
             p++;
         }
         if (full)
-            lz_cut(job, st, p, 0, ZD_CUT_FULL);
+            (void)lz_cut(job, st, p, 0, ZD_CUT_FULL);
     }
     lz_cut_end(job, st, p);
     if (st.nstaged)

@@ -213,7 +213,7 @@ DEV void lz_parse_simple_joints(const LzJob &job, SpLds *lds)
         st.nsyms++;
         p += len >= 3u ? len : 1u;
         if (st.nsyms - st.blk_sym0 == job.cfg.sym_cap)
-            lz_cut(job, st, p, 0, ZD_CUT_FULL);
+            (void)lz_cut(job, st, p, 0, ZD_CUT_FULL);
     }
     lz_cut_end(job, st, p);
     ON_LANE0

@@ -86,6 +86,7 @@ struct SecStream {
     /* outcome */
     bool done = false;
     int status = 0;
+    int broken_line = 0;
     uint32_t delivered = 0, produced = 0;
     std::vector<SecPiece> pieces;
 };
@@ -106,6 +107,7 @@ struct SecSim {
     uint32_t last_end_bit = 0, last_upto = 0, last_cut = 0;
     bool header_done = false, finishing = false, trailer_done = false;
     bool broken = false;
+    int broken_line = 0; /* which consistency check failed (diagnostics) */
     std::vector<SecPiece> pieces;
 
     explicit SecSim(SecStream &stream) : s(stream) {}
@@ -176,7 +178,7 @@ struct SecSim {
             if (!run) {
                 std::map<uint32_t, SecRun>::iterator it = s.runs.find(run_abs);
                 if (it == s.runs.end()) {
-                    broken = true;
+                    broken = true, broken_line = __LINE__;
                     return SEC_Z_STREAM_ERROR;
                 }
                 run = &it->second;
@@ -198,7 +200,7 @@ struct SecSim {
                 data_end = n_cur;
                 if (finish) { /* FLUSH_BLOCK(s, 1) */
                     if (bi >= run->blocks.size() || !run->blocks[bi].last || run->blocks[bi].upto != n_cur) {
-                        broken = true;
+                        broken = true, broken_line = __LINE__;
                         return SEC_Z_STREAM_ERROR;
                     }
                     take_block(run->blocks[bi]);
@@ -218,7 +220,7 @@ struct SecSim {
                         return SEC_Z_OK; /* need_more: the marker is never written (finding 2) */
                 }
                 if ((bi != run->blocks.size() || n_cur != run->n) && si < run->confirmed) {
-                    broken = true; /* the run was parsed for other joints than the ones met */
+                    broken = true, broken_line = __LINE__; /* the run was parsed for other joints than the ones met */
                     return SEC_Z_STREAM_ERROR;
                 }
                 /* block_done with Z_FULL_FLUSH: _tr_stored_block(s, 0, 0, 0), history forgotten.
@@ -281,7 +283,7 @@ struct SecSim {
                         si++;
                         run->confirmed = std::max(run->confirmed, si);
                     } else if (si < run->confirmed) {
-                        broken = true;
+                        broken = true, broken_line = __LINE__;
                         err = SEC_Z_STREAM_ERROR;
                         break;
                     } else {
@@ -301,6 +303,7 @@ struct SecSim {
         if (err == SEC_Z_BUF_ERROR && run && !finishing && produced > run_out0)
             piece(SEC_PIECE_RUN, run_out0, produced - run_out0); /* the caller keeps what fitted */
         s.status = err == SEC_Z_STREAM_END ? SEC_Z_OK : err;
+        s.broken_line = broken_line;
         s.delivered = delivered;
         s.produced = produced;
         s.pieces.swap(pieces);

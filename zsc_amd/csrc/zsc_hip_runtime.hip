@@ -1093,11 +1093,19 @@ extern "C" ZlibReturn zsc_hip_deflate_plan_run(zsc_hip_deflate_plan *pl, const v
                                    pout, (uint32_t *)pl->d_seg_tok.p, (uint16_t *)pl->d_seg_sidx.p,
                                    (const ZdSched *)pl->d_sched.p, cfg, 0u, sb.cseg);
             }
-            ZSC_LAUNCH_PARSE(LzLds, sb.cseg, sb.c36 - sb.cseg);
-            mark();
-            ZSC_LAUNCH_PARSE(LzLds16k, sb.c36, sb.c16 - sb.c36);
-            ZSC_LAUNCH_PARSE(LzLds8k, sb.c16, sb.c8 - sb.c16);
-            ZSC_LAUNCH_PARSE(LzLds4k, sb.c8, sb.count - sb.c8);
+            if (pl->d_sched.p) { /* runs with joints: the parsers keep a hole map (lz_parse.h) */
+                ZSC_LAUNCH_PARSE(LzLdsJ, sb.cseg, sb.c36 - sb.cseg);
+                mark();
+                ZSC_LAUNCH_PARSE(LzLdsJ16k, sb.c36, sb.c16 - sb.c36);
+                ZSC_LAUNCH_PARSE(LzLdsJ8k, sb.c16, sb.c8 - sb.c16);
+                ZSC_LAUNCH_PARSE(LzLdsJ4k, sb.c8, sb.count - sb.c8);
+            } else {
+                ZSC_LAUNCH_PARSE(LzLds, sb.cseg, sb.c36 - sb.cseg);
+                mark();
+                ZSC_LAUNCH_PARSE(LzLds16k, sb.c36, sb.c16 - sb.c36);
+                ZSC_LAUNCH_PARSE(LzLds8k, sb.c16, sb.c8 - sb.c16);
+                ZSC_LAUNCH_PARSE(LzLds4k, sb.c8, sb.count - sb.c8);
+            }
 #undef ZSC_LAUNCH_PARSE
         } else
             hipLaunchKernelGGL(k_parse_fast, dim3(sb.count), dim3(64), 0, st, in, bufs,
