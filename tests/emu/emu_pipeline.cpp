@@ -443,6 +443,7 @@ struct EmuSecRunner {
                 sb.upto = recs[b].in_begin + recs[b].in_len;
                 sb.end_bit = b + 1 < po.nblocks ? plans[b + 1].bit_off : res.bits;
                 sb.wend = recs[b].wend;
+                sb.at = recs[b].at;
                 sb.cut = recs[b].cut;
                 sb.last = recs[b].last;
                 r.blocks.push_back(sb);
@@ -469,6 +470,7 @@ extern "C" int emu_compress_sections(const uint8_t *src, uint32_t n, uint32_t ma
     s.dest_cap = dest_cap;
     s.wrap = wrap;
     s.hdr_len = wrap == 1 ? 2u : wrap == 2 ? (g_gz_hdr_len ? g_gz_hdr_len : 10u) : 0u;
+    s.need = strategy == 2 ? 1u : strategy == 3 ? ZD_MAX_MATCH + 1u : ZD_MIN_LOOKAHEAD;
     EmuSecRunner runner;
     runner.src = src;
     runner.level = level;

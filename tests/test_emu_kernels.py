@@ -20,7 +20,7 @@ def emu():
 
 
 class Rec(C.Structure):
-    _fields_ = [(k, C.c_uint32) for k in ("sym_begin", "sym_count", "in_begin", "in_len", "stored_ok", "last", "cut", "wend")]
+    _fields_ = [(k, C.c_uint32) for k in ("sym_begin", "sym_count", "in_begin", "in_len", "stored_ok", "last", "cut", "wend", "at")]
 
 
 def emu_compress(L, data, level, wrap, strategy=0):

@@ -23,6 +23,15 @@ def oracle_job(job):
     return rc, out, back
 
 
+def inflate_job(job):
+    global _o
+    if _o is None:
+        from oracle.oracle_py import Oracle
+        _o = Oracle()
+    stream, cap, wb = job
+    return _o.uncompress(stream, cap, wb)
+
+
 def main():
     budget = float(sys.argv[1]) if len(sys.argv) > 1 else 60.0
     seed = int(sys.argv[2]) if len(sys.argv) > 2 else 1
@@ -80,6 +89,28 @@ def main():
                 bad += 1
                 print("MISMATCH", "sections" if sections else "batch", j[:2], j[3:], "gpu", st, len(got), "oracle", w[0], len(w[1]), flush=True)
             total += len(b)
+        # the streams the oracle wrote, damaged: the decoder's error paths and resynchronisation
+        if good and rnd.random() < 0.5:
+            hurt, caps2 = [], []
+            for b, w in good:
+                c = bytearray(w[1])
+                if not c:
+                    continue
+                for _ in range(rnd.randrange(1, 4)):
+                    c[rnd.randrange(len(c))] ^= 1 << rnd.randrange(8)
+                if rnd.random() < 0.2:
+                    del c[rnd.randrange(len(c)):]
+                hurt.append(bytes(c))
+                caps2.append(rnd.choice([len(b), len(b) + 50, max(1, len(b) // 2)]))
+            iwb = wb if wb != 8 else 15
+            want2 = pool.map(inflate_job, [(h, c, iwb) for h, c in zip(hurt, caps2)], chunksize=4)
+            irc, outs2, used2, st2 = z.uncompress_batch(hurt, caps2, window_bits=iwb)
+            assert irc == 0
+            for h, c, o2, u2, s2, w in zip(hurt, caps2, outs2, used2, st2, want2):
+                if (s2, o2, u2) != w:
+                    bad += 1
+                    print("MISMATCH inflate of a damaged stream", len(h), c, iwb, "gpu", s2, len(o2), u2, "oracle", w[0], len(w[1]), w[2], flush=True)
+            streams += len(hurt)
         streams += len(jobs)
         batches += 1
         if batches % 10 == 0:

@@ -101,6 +101,7 @@ typedef struct {
     uint32_t pr_hi;     /* rank/hib are staged in LDS for positions below this */
     uint32_t n;         /* input deflate() has been given so far (job.n unless the run has joints) */
     uint32_t si;        /* next joint */
+    uint32_t it;        /* position of the current parse-loop iteration */
 } LzState;
 
 template <class L>
@@ -191,6 +192,18 @@ DEV int lz_put(const LzJob &job, L *lds, LzState &st, uint32_t sym)
 }
 
 /* FLUSH_BLOCK_ONLY, reference src/deflate.c:1660-1668 */
+/* joints of kind 0 that can be folded into the phase that starts now (zsc_dev.h) */
+DEV void lz_fold(const LzJob &job, LzState &st)
+{
+    while (st.si < job.nsched && UNI(job.sched[st.si].kind) == 0u) {
+        const uint32_t jp = UNI(job.sched[st.si].pos);
+        if (jp != ZD_JOINT_ANYWHERE && (uint64_t)jp + ZD_MIN_LOOKAHEAD > st.n)
+            break; /* too close to the end: lz_cut switches at the cut itself */
+        st.n = UNI(job.sched[st.si].new_n);
+        st.si++;
+    }
+}
+
 /* returns the end of the input as it was before, if a joint of kind 0 let the next section in
  * at this cut; 0xffffffff otherwise */
 DEV uint32_t lz_cut(const LzJob &job, LzState &st, uint32_t upto, uint32_t last, uint32_t cut)
@@ -206,6 +219,7 @@ DEV uint32_t lz_cut(const LzJob &job, LzState &st, uint32_t upto, uint32_t last,
         b->stored_ok = st.blk_in0 >= st.base ? 1u : 0u;
         b->last = last;
         b->cut = cut;
+        b->at = cut == ZD_CUT_END ? upto : st.it;
         const uint64_t wend = (uint64_t)st.base + 2ull * job.cfg.wsize;
         b->wend = wend < 0xffffffffull ? (uint32_t)wend : 0xffffffffu;
     }
@@ -219,6 +233,7 @@ DEV uint32_t lz_cut(const LzJob &job, LzState &st, uint32_t upto, uint32_t last,
             joint_n = st.n;
             st.n = UNI(job.sched[st.si].new_n);
             st.si++;
+            lz_fold(job, st);
         }
     }
     return joint_n;
@@ -237,6 +252,7 @@ DEV int lz_joint_at_end(const LzJob &job, LzState &st, uint32_t p)
         (void)lz_cut(job, st, p, 0, ZD_CUT_END);
     st.n = UNI(job.sched[st.si].new_n);
     st.si++;
+    lz_fold(job, st);
     return 1;
 }
 
@@ -575,6 +591,8 @@ DEV void lz_parse_lazy(const LzJob &job, L *lds)
     st.pr_hi = 0;
     st.n = job.nsched ? job.n0 : job.n;
     st.si = 0;
+    st.it = 0;
+    lz_fold(job, st);
 
     uint32_t p = 0, cur_len = 2, cur_at = 0;
     int pending = 0; /* match_available */
@@ -592,6 +610,7 @@ DEV void lz_parse_lazy(const LzJob &job, L *lds)
     const uint32_t last_owner = job.n >= 3 ? job.n - 3 : 0; /* last position that has a rank */
 
     for (;;) {
+        st.it = p;
         uint32_t look = st.data_end - p;
         if (look < ZD_MIN_LOOKAHEAD) {
             lz_refill(job, st, p);
@@ -736,10 +755,13 @@ DEV void lz_parse_greedy(const LzJob &job, LzLdsFast *lds)
     st.pr_hi = 0;
     st.n = job.nsched ? job.n0 : job.n;
     st.si = 0;
+    st.it = 0;
+    lz_fold(job, st);
 
     uint32_t p = 0, len = 0, at = 0;
     uint32_t owed = 0; /* s->insert: strings at the end of a section that wait for their third byte */
     for (;;) {
+        st.it = p;
         uint32_t look = st.data_end - p;
         if (look < ZD_MIN_LOOKAHEAD) {
             lz_refill(job, st, p);

@@ -448,6 +448,7 @@ DEV void sg_parse_segment(const LzJob &job, SgLds *lds, const SgScratch &scr, ui
     st.nsyms = st.nstaged = st.nblocks = st.blk_sym0 = st.blk_in0 = st.pr_hi = 0;
     st.n = job.n;
     st.si = 0;
+    st.it = 0;
 
     const uint32_t S0 = UNI(lds->S0);
     const uint64_t E64 = (uint64_t)S0 + SG_SPAN;
@@ -806,6 +807,7 @@ DEV void sg_append(const LzJob &job, SgOut *o, const uint32_t *tok, uint32_t fro
                 b->last = 0;
                 b->cut = ZD_CUT_FULL;
                 b->wend = wend < 0xffffffffull ? (uint32_t)wend : 0xffffffffu;
+                b->at = last_start + cut_delta;
             }
             nblocks++;
             blk_sym0 = nsyms;
@@ -891,6 +893,7 @@ DEV void sg_phase_resolve(const LzJob &job, SgLds *lds, const SgScratch &scr, in
                 b->last = job.more ? 0u : 1u;
                 b->cut = ZD_CUT_END;
                 b->wend = 0xffffffffu; /* at the end of the input everything given has been read */
+                b->at = job.n;
                 /* a run with joints goes on from here (sg_next_phase) */
                 lds->out.nblocks++;
                 lds->out.blk_sym0 = lds->out.nsyms;
@@ -936,7 +939,7 @@ DEV void sg_next_phase(SgLds *lds, int w, uint32_t from)
 DEV uint32_t sg_phase_end(const LzJob &job, uint32_t n_now, uint32_t *si)
 {
     while (*si < job.nsched && UNI(job.sched[*si].kind) == 0u) {
-        n_now = UNI(job.sched[*si].new_n);
+        n_now = UNI(job.sched[*si].new_n); /* all of them can be folded: sections.h sec_seg_ok */
         (*si)++;
     }
     return n_now;

@@ -52,6 +52,7 @@ DEV void sp_finish(const LzJob &job, SpLds *lds, uint32_t need)
             b->last = job.more ? 0u : 1u;
             b->cut = ZD_CUT_END;
             b->wend = 0xffffffffu;
+            b->at = job.n;
         }
         job.out->nsyms = lds->out.nsyms;
         job.out->nblocks = lds->out.nblocks + cutting;
@@ -175,8 +176,11 @@ DEV void lz_parse_simple_joints(const LzJob &job, SpLds *lds)
     st.pr_hi = 0;
     st.n = job.nsched ? job.n0 : job.n;
     st.si = 0;
+    st.it = 0;
+    lz_fold(job, st);
     uint32_t p = 0;
     for (;;) {
+        st.it = p;
         uint32_t look = st.data_end - p;
         if (look < need) {
             lz_refill(job, st, p);

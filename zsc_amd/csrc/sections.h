@@ -41,6 +41,8 @@
 #include <stdint.h>
 
 #include <algorithm>
+#include <cstdio>
+#include <cstdlib>
 #include <map>
 #include <vector>
 
@@ -51,6 +53,7 @@ struct SecBlock {
     uint32_t upto;     /* first input position after the block (relative to the run) */
     uint32_t end_bit;  /* first bit after the block in the run's own bit stream */
     uint32_t wend;     /* ZdBlockRec.wend */
+    uint32_t at;       /* ZdBlockRec.at */
     uint32_t cut;      /* ZD_CUT_* */
     uint32_t last;
 };
@@ -63,6 +66,7 @@ struct SecRun {
     bool more = false;  /* the stream goes on after it */
     std::vector<ZdSched> sched;
     uint32_t confirmed = 0; /* joints [0, confirmed) were met by the simulation, the rest are speculated */
+    uint32_t no_guess_at = 0xffffffffu; /* a guess of kind 0 failed for the phase that starts with this joint */
     /* filled in by whoever runs the kernels: */
     std::vector<SecBlock> blocks;
     uint32_t round = 0, job = 0; /* where its compressed bytes are */
@@ -82,6 +86,8 @@ struct SecStream {
     uint32_t source_len = 0, max_block_len = 0, dest_cap = 0;
     int wrap = 1;
     uint32_t hdr_len = 0; /* bytes of the zlib / gzip header (a caller's gz_header can be longer than 10) */
+    uint32_t need = ZD_MIN_LOOKAHEAD; /* the parse function calls fill_window when fewer bytes of lookahead are
+                                         left: MIN_LOOKAHEAD, MAX_MATCH + 1 for Z_RLE, 1 for Z_HUFFMAN_ONLY */
     std::map<uint32_t, SecRun> runs; /* by start */
     /* outcome */
     bool done = false;
@@ -130,19 +136,39 @@ struct SecSim {
         if (len)
             pieces.push_back(pc);
     }
-    /* more joints of kind 1 than the simulation has met: one per section end */
-    void speculate(SecRun &r, uint32_t count)
+    /* more joints than the simulation has met.  kind 1: one per section end.  kind 0: somewhere
+     * in the section, far enough from its end for the parsers to fold it (ZD_JOINT_ANYWHERE) --
+     * the phase simply goes on for `count` more sections. */
+    void speculate(SecRun &r, uint32_t count, uint32_t kind = 1u)
     {
         while (count-- != 0 && r.start + r.n < s.source_len) {
             ZdSched j;
-            j.pos = r.n;
+            j.pos = kind == 1u ? r.n : ZD_JOINT_ANYWHERE;
             j.new_n = r.n + std::min(s.max_block_len, s.source_len - (r.start + r.n));
-            j.kind = 1u;
+            j.kind = kind;
             j.pad = 0;
             r.sched.push_back(j);
             r.n = j.new_n;
         }
         r.more = r.start + r.n < s.source_len;
+    }
+    /* was the current phase parsed with more input than deflate() has been given (a guessed
+     * joint of kind 0 that has not happened yet)? */
+    bool phase_guessed() const
+    {
+        return run && si < run->sched.size() && run->sched[si].kind == 0u &&
+               run->sched[si].pos == ZD_JOINT_ANYWHERE;
+    }
+    /* the guess did not come true: parse the run again with what is known, no guess for this phase */
+    SecRun *retract = nullptr;
+    void give_up_guess()
+    {
+        run->sched.resize(si);
+        run->confirmed = std::min<uint32_t>(run->confirmed, si);
+        run->n = given - run_abs;
+        run->more = given < s.source_len;
+        run->no_guess_at = si;
+        retract = run;
     }
     void take_block(const SecBlock &b)
     {
@@ -150,7 +176,12 @@ struct SecSim {
         last_end_bit = b.end_bit;
         last_upto = b.upto;
         last_cut = b.cut;
-        data_end = std::min(b.wend, given - run_abs);
+        /* how far has fill_window read?  It is only called when the lookahead runs low, so after
+         * the input has grown at a joint of kind 0 the old figure stands until the parse comes that
+         * close to the OLD end; and the window only moves in fill_window, so its end as recorded
+         * at this cut is its end at the last call. */
+        if ((uint64_t)data_end < (uint64_t)b.at + s.need)
+            data_end = std::min(b.wend, given - run_abs);
         bi++;
     }
 
@@ -190,6 +221,10 @@ struct SecSim {
             for (;;) {
                 if (bi < run->blocks.size() && run->blocks[bi].cut == ZD_CUT_FULL &&
                     run->blocks[bi].upto <= n_cur) {
+                    if (phase_guessed() && (uint64_t)run->blocks[bi].upto + ZD_MIN_LOOKAHEAD > n_cur) {
+                        give_up_guess(); /* cut too close to the real end to be what the reference does */
+                        return SEC_Z_STREAM_ERROR;
+                    }
                     take_block(run->blocks[bi]); /* FLUSH_BLOCK(s, 0) inside deflate_slow/_fast/... */
                     flush_pending();
                     if (avail_out == 0)
@@ -197,6 +232,10 @@ struct SecSim {
                     continue;
                 }
                 /* the input given so far is used up */
+                if (phase_guessed()) {
+                    give_up_guess(); /* the parse went on as if there were more */
+                    return SEC_Z_STREAM_ERROR;
+                }
                 data_end = n_cur;
                 if (finish) { /* FLUSH_BLOCK(s, 1) */
                     if (bi >= run->blocks.size() || !run->blocks[bi].last || run->blocks[bi].upto != n_cur) {
@@ -277,8 +316,16 @@ struct SecSim {
                     j.new_n = given - run_abs;
                     j.kind = last_cut == ZD_CUT_END ? 1u : 0u;
                     j.pad = 0;
-                    const bool known = si < run->sched.size() && run->sched[si].pos == j.pos &&
-                                       run->sched[si].new_n == j.new_n && run->sched[si].kind == j.kind;
+                    if (getenv("ZSC_SEC_DEBUG"))
+                        fprintf(stderr, "sim: joint kind %u at %u (run %u): n %u -> %u, produced %u delivered %u\n", j.kind,
+                                j.pos, run->start, j.new_n - take, j.new_n, produced, delivered);
+                    bool known = si < run->sched.size() && run->sched[si].pos == j.pos &&
+                                 run->sched[si].new_n == j.new_n && run->sched[si].kind == j.kind;
+                    if (!known && phase_guessed() && j.kind == 0u && run->sched[si].new_n == j.new_n &&
+                        (uint64_t)j.pos + ZD_MIN_LOOKAHEAD <= j.new_n - take) {
+                        run->sched[si].pos = j.pos; /* the guess came true, here */
+                        known = true;
+                    }
                     if (known) {
                         si++;
                         run->confirmed = std::max(run->confirmed, si);
@@ -293,12 +340,20 @@ struct SecSim {
                         run->sched.push_back(j);
                         run->confirmed = si + 1;
                         run->n = j.new_n;
-                        speculate(*run, run->confirmed);
+                        /* what happened once tends to happen again: the same kind of joint, as
+                         * many times as the run has confirmed joints */
+                        if (!getenv("ZSC_SEC_NO_GUESS") && j.kind == 0u && run->no_guess_at != si + 1 &&
+                            (uint64_t)j.pos + ZD_MIN_LOOKAHEAD <= j.new_n - take)
+                            speculate(*run, run->confirmed, 0u); /* only what the parsers can fold */
+                        else
+                            speculate(*run, run->confirmed, 1u);
                         return run;
                     }
                 }
             }
             err = deflate(left_src == 0);
+            if (retract)
+                return retract;
         }
         if (err == SEC_Z_BUF_ERROR && run && !finishing && produced > run_out0)
             piece(SEC_PIECE_RUN, run_out0, produced - run_out0); /* the caller keeps what fitted */
@@ -320,7 +375,8 @@ static inline bool sec_seg_ok(const SecRun &r)
 {
     uint32_t n_old = r.n0;
     for (size_t i = 0; i < r.sched.size(); i++) {
-        if (r.sched[i].kind == 0u && r.sched[i].pos + ZD_MIN_LOOKAHEAD > n_old)
+        if (r.sched[i].kind == 0u && r.sched[i].pos != ZD_JOINT_ANYWHERE &&
+            (uint64_t)r.sched[i].pos + ZD_MIN_LOOKAHEAD > n_old)
             return false;
         n_old = r.sched[i].new_n;
     }
@@ -364,7 +420,7 @@ static inline int sec_compress(std::vector<SecStream> &streams, RUNNER &runner)
     uint64_t max_rounds = 2;
     for (size_t i = 0; i < streams.size(); i++) {
         sec_first_runs(streams[i], (uint32_t)i, jobs);
-        max_rounds = std::max<uint64_t>(max_rounds, streams[i].runs.size() + 2);
+        max_rounds = std::max<uint64_t>(max_rounds, 2 * streams[i].runs.size() + 4);
     }
     for (uint32_t round = 0; !jobs.empty(); round++) {
         if (round > max_rounds)

@@ -83,7 +83,13 @@ typedef struct {
  * following the output slices (sections.h):
  *   kind 0  when the block that is cut at `pos` for being full has been flushed
  *   kind 1  when the input given so far is used up (at `pos`): the owed literal goes out, the
- *           block is cut if it holds anything, and the parse carries on with the history */
+ *           block is cut if it holds anything, and the parse carries on with the history
+ * A joint of kind 0 whose cut lies MIN_LOOKAHEAD or more before the old end cannot have been
+ * noticed by the parse before it -- the end of the input only shows within MIN_LOOKAHEAD of it
+ * (lookahead caps, fill_window calls) -- so the parsers "fold" it: they take the new length from
+ * the start of the phase.  pos == ZD_JOINT_ANYWHERE marks one the host only guesses (sections.h):
+ * folded too, and checked against what really happens afterwards. */
+#define ZD_JOINT_ANYWHERE 0xffffffffu
 typedef struct {
     uint32_t pos;   /* relative to the start of the run */
     uint32_t new_n; /* the run's length from then on */
@@ -108,6 +114,8 @@ typedef struct {
     uint32_t cut;      /* 0: the block was full (lit_bufsize - 1 symbols), 1: the input ended */
     uint32_t wend;     /* end of the window (base + 2 * w_size) when the block was cut: fill_window had
                           read up to there, or to the end of the input given so far if that is less */
+    uint32_t at;       /* position of the parse-loop iteration that cut the block (the last one whose
+                          fill_window call, if any, the window end above reflects) */
 } ZdBlockRec;
 
 #define ZD_CUT_FULL 0u

@@ -1672,6 +1672,7 @@ struct HipSecRunner {
                 blk.upto = rec.in_begin + rec.in_len;
                 blk.end_bit = k + 1 < pout[j].nblocks ? bit_off[b.blk0 + k + 1] : res[j].bits;
                 blk.wend = rec.wend;
+                blk.at = rec.at;
                 blk.cut = rec.cut;
                 blk.last = rec.last;
                 r.blocks.push_back(blk);
@@ -1730,6 +1731,7 @@ static ZlibReturn sections_on_device(U32 count, const uint8_t *d_src, const uint
         s.dest_cap = dest_caps[i];
         s.wrap = wrap;
         s.hdr_len = wrap == 1 ? 2u : wrap == 2 ? (gzip_header_len ? gzip_header_len : 10u) : 0u;
+        s.need = strategy == Z_HUFFMAN_ONLY ? 1u : strategy == Z_RLE ? ZD_MAX_MATCH + 1u : ZD_MIN_LOOKAHEAD;
         memset(&sbufs[i], 0, sizeof(ZdBuf));
         sbufs[i].in_off = src_off[i];
         sbufs[i].in_len = source_lens[i];
