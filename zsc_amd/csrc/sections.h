@@ -33,6 +33,22 @@
  * that is parsed again gets as many as it has confirmed ones, so an incompressible stream,
  * where every section end is a joint, takes log2(sections) rounds instead of one per section.
  *
+ * Joints of kind 0 do not sit at section ends, so they cannot be listed ahead.  But a joint
+ * whose cut lies MIN_LOOKAHEAD or more before the old end of the input cannot have been noticed
+ * by the parse before it (the end only shows in lookahead caps and fill_window calls, both
+ * within MIN_LOOKAHEAD of it): every parser "folds" such a joint -- takes the new length from
+ * the start of the phase -- and the host may guess one (ZD_JOINT_ANYWHERE: "this phase goes on
+ * for another section").  The simulation then checks every block of a guessed phase: one cut
+ * within MIN_LOOKAHEAD of the real end, or the real end reached with the guess still open, and
+ * the run is parsed again without it.  With that an incompressible stream, where nearly every
+ * output slice ends in a joint, costs a few extra parses instead of one per joint.
+ *
+ * What fill_window has read (the wrapper's "avail_in == 0") is followed statefully: it is only
+ * called when the lookahead runs low, so after a joint of kind 0 the old figure stands until
+ * the parse comes within MIN_LOOKAHEAD of the OLD end -- a second block that fills up before
+ * that is not a joint.  Block records carry the window end and the position of the parse-loop
+ * iteration that cut them (the window only moves inside fill_window).
+ *
  * Plain C++, no HIP: the kernels' lane-emulation build (tests/emu) runs the same code.
  */
 #ifndef ZSC_SECTIONS_H
