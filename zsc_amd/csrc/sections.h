@@ -57,8 +57,6 @@
 #include <stdint.h>
 
 #include <algorithm>
-#include <cstdio>
-#include <cstdlib>
 #include <map>
 #include <vector>
 
@@ -332,9 +330,6 @@ struct SecSim {
                     j.new_n = given - run_abs;
                     j.kind = last_cut == ZD_CUT_END ? 1u : 0u;
                     j.pad = 0;
-                    if (getenv("ZSC_SEC_DEBUG"))
-                        fprintf(stderr, "sim: joint kind %u at %u (run %u): n %u -> %u, produced %u delivered %u\n", j.kind,
-                                j.pos, run->start, j.new_n - take, j.new_n, produced, delivered);
                     bool known = si < run->sched.size() && run->sched[si].pos == j.pos &&
                                  run->sched[si].new_n == j.new_n && run->sched[si].kind == j.kind;
                     if (!known && phase_guessed() && j.kind == 0u && run->sched[si].new_n == j.new_n &&
@@ -358,7 +353,7 @@ struct SecSim {
                         run->n = j.new_n;
                         /* what happened once tends to happen again: the same kind of joint, as
                          * many times as the run has confirmed joints */
-                        if (!getenv("ZSC_SEC_NO_GUESS") && j.kind == 0u && run->no_guess_at != si + 1 &&
+                        if (j.kind == 0u && run->no_guess_at != si + 1 &&
                             (uint64_t)j.pos + ZD_MIN_LOOKAHEAD <= j.new_n - take)
                             speculate(*run, run->confirmed, 0u); /* only what the parsers can fold */
                         else
