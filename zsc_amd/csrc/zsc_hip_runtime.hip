@@ -1717,6 +1717,17 @@ static ZlibReturn sections_on_device(U32 count, const uint8_t *d_src, const uint
     zh += 31u - zh % 31u;
     const uint32_t xfl = level == 9 ? 2u : (strategy >= Z_HUFFMAN_ONLY || level < 2) ? 4u : 0u;
 
+    /* the host keeps a record per section: refuse what would not fit there, loudly */
+    uint64_t nsections = 0;
+    for (U32 i = 0; i < count; i++) {
+        ZSC_ASSERT(max_block_lens[i] != 0);
+        nsections += source_lens[i] / max_block_lens[i] + 1u;
+    }
+    if (nsections > (64ull << 20)) {
+        ZSC_WARN1("zsc_hip: %llu sections in one call are more than the host side keeps track of.",
+                  (unsigned long long)nsections);
+        return Z_MEM_ERROR;
+    }
     std::vector<SecStream> streams(count);
     std::vector<ZdBuf> sbufs(count);
     for (U32 i = 0; i < count; i++) {
