@@ -335,3 +335,16 @@ def test_sections_behind_a_callers_gzip_header(z):
         rc, out = z.compress2(data, max_block_len=c["max_block_len"], level=c["level"], window_bits=31,
                               gz_header=h, dest_len=c["dest_cap"])
         assert (rc, len(out), sha(out)) == (c["rc"], c["out_len"], c["out_sha256"]), c
+
+
+def test_short_soak():
+    """tools/soak.py for a quarter of a minute with a fixed seed: random sizes, classes, levels,
+    wrappers, window_bits, mem_level, strategies, section lengths and dest capacities against the
+    oracle, and the decoder on damaged copies of the streams (it found the hole-map and the
+    data_end corners of the sections path; see DESIGN.md for the long runs)."""
+    import subprocess
+    import sys
+    root = os.path.dirname(HERE)
+    r = subprocess.run([sys.executable, os.path.join(root, "tools", "soak.py"), "15", "11"],
+                       capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0 and " 0 mismatches" in r.stdout, (r.stdout[-600:], r.stderr[-600:])
