@@ -50,13 +50,18 @@ def main():
         strat = rnd.choice([0, 0, 0, 1, 4, 2, 3]) if ml >= 8 else rnd.choice([0, 0, 1])
         sections = rnd.random() < 0.5
         jobs = []
-        for i in range(rnd.choice([8, 32, 96])):
+        big = os.environ.get("SOAK_BIG") is not None  # few long streams instead of many short ones
+        for i in range(rnd.choice([8, 16]) if big else rnd.choice([8, 32, 96])):
             n = rnd.choice([0, 1, 2, 3, 100, 259, 4000, 18432, 18433, 32768, 65535, 65536, 65537, 100000,
                             rnd.randrange(1, 300000), rnd.randrange(1, 2 << 20)])
+            if big:
+                n = rnd.randrange(1 << 20, 8 << 20)
             kind = rnd.choice(KINDS)
             if sections and n > 1:
                 mbl = rnd.choice([rnd.randrange(1, 100), rnd.randrange(100, 5000), rnd.randrange(5000, 70000),
                                   rnd.randrange(60000, 400000), 32768, 65536, 100000])
+                if big:
+                    mbl = rnd.choice([16384, 32768, 65536, 100000, 262144, 1 << 20, rnd.randrange(20000, 2 << 20)])
                 mbl = max(1, min(mbl, n - 1))
                 if n // mbl > 400:
                     mbl = n // 400 + 1
