@@ -32,7 +32,7 @@
 #include "wave.h"
 #include "zsc_dev.h"
 
-#define HS_WAVES 4
+#define HS_WAVES 16
 
 typedef struct {
     uint32_t cnt0[256 * HS_WAVES];
