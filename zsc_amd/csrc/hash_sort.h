@@ -136,6 +136,10 @@ DEV void hs_scatter(const HsTile &t, HsLds *lds, int w, int pass)
             if (LV(ok)) {
                 if (pass == 0) {
                     t.tmp[LV(dst)] = LV(ent);
+                    /* the second pass counts its digits per wave slice of tmp: where this entry
+                     * lands decides the slice, so that count is taken here and the counting
+                     * pass over tmp is saved */
+                    LDS_ADD_U32(&lds->cnt1[(LV(ent) >> 24) * HS_WAVES + LV(dst) / slice], 1u);
                 } else {
                     t.sorted[LV(dst)] = LV(ent);
                     t.rank[t.start + (LV(ent) & ZD_TILE_MASK)] = (uint16_t)LV(dst);
@@ -258,8 +262,7 @@ DEV void hash_sort_phase(const HsTile &t, HsLds *lds, int w, int phase)
         hs_scatter(t, lds, w, 0);
         break;
     case 4:
-        hs_count(t, lds, w, 1);
-        break;
+        break; /* counted while scattering (hs_scatter, pass 0) */
     case 5:
         if (w == 0)
             hs_scan(lds->cnt1, 128);
