@@ -101,6 +101,8 @@ static inline uint32_t lds_u32(const uint8_t *base, uint32_t idx)
 #define LDS_FETCH_ADD_U32(ptr, v) ((*(ptr) += (v)) - (v)) /* returns the old value */
 #define LDS_OR_U32(ptr, v) (*(ptr) |= (v))
 #define GLOBAL_OR_U32(ptr, v) (*(ptr) |= (v))
+#define LDS_STORE_REL(ptr, v) (*(ptr) = (v))
+#define LDS_LOAD_ACQ(ptr) (*(ptr))
 #define CTZ64(x) __builtin_ctzll(x)
 #define CTZ32(x) __builtin_ctz(x)
 #define POPC64(x) __builtin_popcountll(x)
@@ -197,6 +199,10 @@ DEV uint32_t lds_u32(const uint8_t *base, uint32_t idx)
 #define LDS_FETCH_ADD_U32(ptr, v) atomicAdd((ptr), (v))
 #define LDS_OR_U32(ptr, v) atomicOr((ptr), (v))
 #define GLOBAL_OR_U32(ptr, v) atomicOr((ptr), (v))
+/* a word in LDS through which one wave tells the others of its workgroup how far it has got:
+ * what it stored to LDS before the release is there for whoever sees the new value */
+#define LDS_STORE_REL(ptr, v) __hip_atomic_store((ptr), (v), __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP)
+#define LDS_LOAD_ACQ(ptr) __hip_atomic_load((ptr), __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP)
 #define CTZ64(x) __builtin_ctzll(x)
 #define CTZ32(x) __builtin_ctz(x)
 #define POPC64(x) __builtin_popcountll(x)
