@@ -37,7 +37,7 @@ static inline void sg_count(int what, unsigned n)
 #include "../../zsc_amd/csrc/lz_parse_seg.h"
 /* lane-parallel parser: [1] candidates, [2] passers, [3] compare steps, [4] rounds, [5] advance blocks,
  * [6] walk blocks, [7] compare blocks, [8] heavy searches, [9]/[10]/[11] lanes active in those blocks */
-extern "C" { unsigned long long g_sl_cnt[16]; unsigned long long g_sl_hist[65]; unsigned g_sl_lane[1024], g_sl_call[1024]; unsigned long long g_sl_bal[8]; }
+extern "C" { unsigned long long g_sl_cnt[16]; unsigned long long g_sl_hist[65]; unsigned g_sl_lane[1024], g_sl_call[1024], g_sl_modes[1024][8]; unsigned long long g_sl_bal[8]; unsigned long long g_sl_slow[8], g_sl_all[8], g_sl_bulk[8]; }
 #define SL_COUNT(what, n) (g_sl_cnt[what] += (n), (what) == 10 ? g_sl_hist[(n)]++ : 0ull)
 #include "../../zsc_amd/csrc/lz_parse_lane.h"
 #include "../../zsc_amd/csrc/lz_parse_simple.h"
@@ -226,6 +226,16 @@ static void run_parse_lane(const LzJob &job)
                 for (unsigned i = 0; i < 64; i++)
                     m = g_sl_lane[w * 64 + i] > m ? g_sl_lane[w * 64 + i] : m;
                 g_wave_sum_max += m * 64;
+            }
+            {
+                unsigned worst = 0;
+                for (unsigned i = 0; i < SL_NS; i++)
+                    if (g_sl_lane[i] > g_sl_lane[worst]) worst = i;
+                for (int k = 0; k < 8; k++) {
+                    g_sl_slow[k] += g_sl_modes[worst][k];
+                    for (unsigned i = 0; i < SL_NS; i++) { g_sl_all[k] += g_sl_modes[i][k]; }
+                }
+                memset(g_sl_modes, 0, sizeof g_sl_modes);
             }
             for (unsigned i = 0; i < SL_NS; i++) {
                 sum += g_sl_lane[i];

@@ -50,6 +50,11 @@
 #ifndef SL_COUNT
 #define SL_COUNT(what, n) /* event counters of the host emulation (tests/emu) */
 #endif
+#ifdef ZSC_WAVE_EMU
+#define SL_BULK_STAT(k) (g_sl_bulk[k]++)
+#else
+#define SL_BULK_STAT(k)
+#endif
 
 #ifndef SL_W
 #define SL_W 4 /* waves per workgroup */
@@ -71,6 +76,13 @@
 #endif
 #ifndef SL_HEAVY_AFTER
 #define SL_HEAVY_AFTER 24u /* ... once the lane has looked at this many candidates itself */
+#endif
+#define SL_NBULK 8u
+#ifndef SL_USE_BULK
+#define SL_USE_BULK 0
+#endif
+#ifndef SL_BULK_MIN
+#define SL_BULK_MIN 16u /* a chain with at least this many candidates left (and its first block done) is walked 64 at a time */
 #endif
 #ifndef SL_STEPS
 #define SL_STEPS 4 /* looks / compare steps a lane may take per round */
@@ -135,6 +147,15 @@ typedef struct {
     LANEVAR(uint32_t, pm1_at);
     LANEVAR(uint32_t, pmj_at);
     LANEVAR(uint32_t, hvy_ok); /* the search has not been considered for the whole wave yet */
+    LANEVAR(uint32_t, bslot);  /* the bulk slot that works for this lane, or SL_NONE */
+    LANEVAR(uint32_t, bk0);    /* the entries of the bulk slots: lane l holds entry l of each */
+    LANEVAR(uint32_t, bk1);
+    LANEVAR(uint32_t, bk2);
+    LANEVAR(uint32_t, bk3);
+    LANEVAR(uint32_t, bk4);
+    LANEVAR(uint32_t, bk5);
+    LANEVAR(uint32_t, bk6);
+    LANEVAR(uint32_t, bk7);
     LANEVAR(uint32_t, cq);
     LANEVAR(uint32_t, coff);
 } SlWave;
@@ -164,6 +185,11 @@ typedef struct {
     uint4 par[WAVE];            /* x: position of entry value 0, y: best_len - 1, z: the two bytes, w: floor */
     uint16_t own[WAVE * 8];     /* candidate i of the round belongs to lane own[i] & 255, its entry number own[i] >> 8 */
     uint32_t res[WAVE];         /* bit k: the lane's k-th candidate needs a look by its lane; bit 8 + k: it lies outside the window */
+    /* long chains: the next 64 candidates of up to SL_NBULK lanes, one per lane of the wave */
+    uint32_t bown[SL_NBULK];    /* the lane a slot works for, or SL_NONE */
+    uint32_t bvn[SL_NBULK];     /* the candidate number of the slot's first entry */
+    uint32_t bcnt[SL_NBULK];    /* entries in the slot */
+    uint32_t bnew[SL_NBULK];    /* asked for in this round: looked at in the next one */
 } SlStage;
 
 struct SlLds {
@@ -713,6 +739,9 @@ DEV void sl_parse_start(const LzJob &job, SlLds *lds, int w, SlWave &ws)
         LV(ws.pm1) = LV(ws.pmj) = 0;
         LV(ws.pm1_at) = LV(ws.pmj_at) = SL_NONE;
         LV(ws.hvy_ok) = 0;
+        LV(ws.bslot) = SL_NONE;
+        LV(ws.bk0) = LV(ws.bk1) = LV(ws.bk2) = LV(ws.bk3) = 0;
+        LV(ws.bk4) = LV(ws.bk5) = LV(ws.bk6) = LV(ws.bk7) = 0;
         if (s == 0) {
             LV(ws.p) = sp;
             LV(ws.cur_len) = slen;
@@ -738,8 +767,96 @@ DEV void sl_parse_start(const LzJob &job, SlLds *lds, int w, SlWave &ws)
             }
         }
     }
+    ON_LANE0
+    {
+        for (uint32_t i = 0; i < SL_NBULK; i++)
+            lds->stage[w].bown[i] = SL_NONE;
+    }
     WAVE_SYNC();
 }
+
+/* Bulk slots.  A lane whose chain is long would need a round per eight candidates; instead the
+ * wave fetches the next 64 entries of such a chain with one coalesced load, lane l entry l, and
+ * looks at them in the next round: one ballot finds the first candidate that does not fail the
+ * pre-check (or lies outside the window), the lane takes over from there. */
+#define SL_BULK_LOAD(I, BK)                                                                   \
+    do {                                                                                      \
+        if (UNI(sg->bnew[I]) != 0u && UNI(sg->bown[I]) != SL_NONE) {                          \
+            const int _h = (int)UNI(sg->bown[I]);                                             \
+            const uint32_t _vn = UNI(sg->bvn[I]), _cnt = UNI(sg->bcnt[I]);                    \
+            const uint32_t _p = READLANE(ws.p, _h), _nA = READLANE(ws.nA, _h);                \
+            const int32_t _hiA = READLANE(ws.hiA, _h), _hiB = READLANE(ws.hiB, _h);           \
+            const uint16_t *_run = job.sorted16 + (uint64_t)(_p >> 15) * ZD_TILE;             \
+            FOR_LANES                                                                         \
+            {                                                                                 \
+                const uint32_t _v = _vn + (uint32_t)LANE;                                     \
+                const int32_t _j = _v < _nA ? _hiA - (int32_t)_v : _hiB - (int32_t)(_v - _nA) - (int32_t)ZD_TILE; \
+                LV(BK) = (uint32_t)LANE < _cnt ? (uint32_t)_run[_j] : 0u;                     \
+            }                                                                                 \
+        }                                                                                     \
+    } while (0)
+
+#define SL_BULK_EVAL(I, BK)                                                                   \
+    do {                                                                                      \
+        if (UNI(sg->bown[I]) != SL_NONE && UNI(sg->bnew[I]) == 0u) {                          \
+            const int _h = (int)UNI(sg->bown[I]);                                             \
+            const uint32_t _vn = UNI(sg->bvn[I]), _cnt = UNI(sg->bcnt[I]);                    \
+            const uint32_t _vh = READLANE(ws.v, _h), _lh = READLANE(ws.left, _h), _mh = READLANE(ws.mode, _h); \
+            SL_BULK_STAT((_mh == SL_SRCH && _lh == 0u && _vh == _vn) ? 0 : _mh != SL_SRCH ? 1 : _lh != 0u ? 2 : 3); \
+            if (_mh == SL_SRCH && _lh == 0u && _vh == _vn) {                                  \
+                const uint32_t _p = READLANE(ws.p, _h), _nA = READLANE(ws.nA, _h);            \
+                const uint32_t _qb = (_p & ~ZD_TILE_MASK) - (_vn < _nA ? 0u : ZD_TILE);       \
+                const uint32_t _boff = READLANE(ws.best, _h) - 1u, _sb = READLANE(ws.sb, _h); \
+                const uint32_t _fl = READLANE(ws.floor_pos, _h), _tot = READLANE(ws.total, _h); \
+                LANEVAR(int, _ev);                                                            \
+                LANEVAR(int, _dd);                                                            \
+                SL_COUNT(6, 1);                                                               \
+                SL_COUNT(10, _cnt);                                                           \
+                SL_COUNT(1, _cnt);                                                            \
+                FOR_LANES                                                                     \
+                {                                                                             \
+                    const uint32_t _q = _qb + LV(BK);                                         \
+                    const int _in = (uint32_t)LANE < _cnt;                                    \
+                    const int _dead = _in && _q <= _fl;                                       \
+                    const uint32_t _g = SL_U32(((_dead || !_in) ? _fl + 1u : _q) + _boff) & 0xffffu; \
+                    LV(_dd) = _dead;                                                          \
+                    LV(_ev) = _dead || (_in && _g == _sb);                                    \
+                }                                                                             \
+                const uint64_t _m = BALLOT(_ev), _md = BALLOT(_dd);                           \
+                const uint32_t _e = _m ? (uint32_t)CTZ64(_m) : _cnt;                          \
+                const int _leaves = _m != 0 && ((_md >> _e) & 1ull) != 0;                     \
+                const uint32_t _ent = READLANE(BK, _m ? _e : 0u);                             \
+                const uint32_t _qlast = _qb + READLANE(BK, _cnt - 1u);                        \
+                FOR_LANES                                                                     \
+                {                                                                             \
+                    if (LANE == _h) {                                                         \
+                        LV(ws.v) = _vn + _e;                                                  \
+                        if (_leaves || _vn + _e == _tot) {                                    \
+                            LV(ws.mode) = SL_ADV2; /* the chain leaves the window, or ends */ \
+                        } else if (_m != 0) {                                                 \
+                            LV(ws.E).w = _ent << 16;                                          \
+                            LV(ws.left) = 1;                                                  \
+                            LV(ws.mode) = SL_LOOK;                                            \
+                        } else if (LV(ws.hvy_ok) != 0u && _vn + _e >= SL_HEAVY_AFTER && _qlast > _fl + 1u && \
+                                   _tot - (_vn + _e) >= SL_HEAVY &&                           \
+                                   _tot - (_vn + _e) > 128u * ((_qlast - _fl) / 1024u + 2u)) { \
+                            /* what is left is long and dense: the window sweep, from behind the \
+                             * last candidate looked at */                                    \
+                            LV(ws.hvy_ok) = 0;                                                \
+                            LV(ws.cq) = _qlast - 1u;                                          \
+                            LV(ws.mode) = SL_HVY;                                             \
+                        }                                                                     \
+                    }                                                                         \
+                }                                                                             \
+            }                                                                                 \
+            FOR_LANES                                                                         \
+            {                                                                                 \
+                if (LANE == _h)                                                               \
+                    LV(ws.bslot) = SL_NONE;                                                   \
+            }                                                                                 \
+            ON_LANE0 { sg->bown[I] = SL_NONE; }                                               \
+        }                                                                                     \
+    } while (0)
 
 /* one round of wave w's loop; returns 1 when all its lanes are done */
 DEV int sl_parse_round(const LzJob &job, SlLds *lds, const SlScratch &scr, int w, SlWave &ws)
@@ -779,6 +896,26 @@ DEV int sl_parse_round(const LzJob &job, SlLds *lds, const SlScratch &scr, int w
             sl_heavy(job, lds, ws, wrap_base, hl);
         }
     }
+    /* 0: the bulk slots filled in the previous round (every load of that round has landed: its
+     * last step waited for them -- nothing here waits for a load issued in this round) */
+    SlStage *sg = &lds->stage[w];
+#if SL_USE_BULK
+    ON_LANE0
+    {
+        for (uint32_t i = 0; i < SL_NBULK; i++)
+            sg->bnew[i] = 0;
+    }
+    WAVE_SYNC();
+    SL_BULK_EVAL(0, ws.bk0);
+    SL_BULK_EVAL(1, ws.bk1);
+    SL_BULK_EVAL(2, ws.bk2);
+    SL_BULK_EVAL(3, ws.bk3);
+    SL_BULK_EVAL(4, ws.bk4);
+    SL_BULK_EVAL(5, ws.bk5);
+    SL_BULK_EVAL(6, ws.bk6);
+    SL_BULK_EVAL(7, ws.bk7);
+    WAVE_SYNC();
+#endif
     /* 1: the advance block, for the lanes at a loop top -- when enough of them are */
     if ((m_adv != 0 && (POPC64(m_adv) >= SL_ADV_MIN || m_old != 0 || m_busy == 0)) || (m_wait != 0 && m_busy == 0 && m_adv == 0)) {
         SL_COUNT(5, 1);
@@ -794,10 +931,56 @@ DEV int sl_parse_round(const LzJob &job, SlLds *lds, const SlScratch &scr, int w
             }
         }
     }
-    /* 2: ask for the block of entries behind the one a lane is working through */
+    /* 2: ask for what a lane looks at next: 64 entries at once for a few lanes with long chains
+     * (bulk slots), for the others the block of eight behind the one they are working through */
+#if SL_USE_BULK
+    {
+        LANEVAR(int, f_want);
+        LANEVAR(int, f_long);
+        FOR_LANES
+        {
+            const uint32_t vn = LV(ws.v) + LV(ws.left);
+            LV(f_want) = LV(ws.mode) == SL_SRCH && LV(ws.bslot) == SL_NONE && LV(ws.v) != 0u &&
+                         vn < LV(ws.total) && LV(ws.total) - vn >= SL_BULK_MIN;
+            LV(f_long) = LV(f_want) && LV(ws.total) - vn >= 64u;
+        }
+        uint64_t want = BALLOT(f_want), wlong = BALLOT(f_long);
+        for (uint32_t i = 0; i < SL_NBULK && want != 0; i++) {
+            if (UNI(sg->bown[i]) != SL_NONE)
+                continue;
+            /* the longest chains gain most */
+            const int h = wlong != 0 ? CTZ64(wlong) : CTZ64(want);
+            want &= ~(1ull << h);
+            wlong &= ~(1ull << h);
+            FOR_LANES
+            {
+                if (LANE == h) {
+                    const uint32_t vn = LV(ws.v) + LV(ws.left);
+                    const uint32_t in_run = vn < LV(ws.nA) ? LV(ws.nA) - vn : LV(ws.total) - vn;
+                    sg->bown[i] = (uint32_t)h;
+                    sg->bvn[i] = vn;
+                    sg->bcnt[i] = in_run < 64u ? in_run : 64u;
+                    sg->bnew[i] = 1;
+                    LV(ws.bslot) = i;
+                }
+            }
+            WAVE_SYNC();
+        }
+        SL_BULK_LOAD(0, ws.bk0);
+        SL_BULK_LOAD(1, ws.bk1);
+        SL_BULK_LOAD(2, ws.bk2);
+        SL_BULK_LOAD(3, ws.bk3);
+        SL_BULK_LOAD(4, ws.bk4);
+        SL_BULK_LOAD(5, ws.bk5);
+        SL_BULK_LOAD(6, ws.bk6);
+        SL_BULK_LOAD(7, ws.bk7);
+    }
+#else
+    (void)sg;
+#endif
     FOR_LANES
     {
-        if (LV(ws.mode) == SL_SRCH || LV(ws.mode) == SL_CMP || LV(ws.mode) == SL_LOOK) {
+        if ((LV(ws.mode) == SL_SRCH || LV(ws.mode) == SL_CMP || LV(ws.mode) == SL_LOOK) && LV(ws.bslot) == SL_NONE) {
             const uint32_t vn = LV(ws.v) + LV(ws.left);
             if (vn < LV(ws.total) && LV(ws.n_for) != vn) {
                 const uint16_t *runA = job.sorted16 + (uint64_t)(LV(ws.p) >> 15) * ZD_TILE;
@@ -813,6 +996,10 @@ DEV int sl_parse_round(const LzJob &job, SlLds *lds, const SlScratch &scr, int w
     FOR_LANES
     {
         const uint32_t m = LV(ws.mode);
+        if (m != SL_DONE) {
+            g_sl_lane[LV(ws.slot)]++;
+            g_sl_modes[LV(ws.slot)][m == SL_ADV || m == SL_ADV2 || m == SL_WAIT ? 0 : m == SL_SRCH && LV(ws.left) == 0 ? (LV(ws.bslot) != SL_NONE ? 1 : 2) : m == SL_SRCH ? 3 : m == SL_LOOK ? 4 : m == SL_CMP ? 5 : 6]++;
+        }
         SL_COUNT(12, m == SL_DONE);
         SL_COUNT(13, m == SL_ADV || m == SL_ADV2 || m == SL_WAIT);
         SL_COUNT(14, m == SL_SRCH && LV(ws.left) == 0);
