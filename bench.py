@@ -20,6 +20,14 @@ Rank 0 prints ONE JSON line:  value = uncompressed MB/s in, whole job.
   cpu_baseline  the same workload on the host cores: the compiled reference when
                 oracle/_ref/libzsc_ref.so travelled with the repo ("reference"),
                 otherwise the byte-identical oracle ("port"); bounded sample.
+  checked       every distinct buffer of the timed batch against the oracle, and every
+                replica against its first copy on the device.
+With one GPU the line also carries the rest of BASELINE's metric (untimed by the headline):
+  inflate       BASELINE config 4: gzip members of 4-64 KiB (made by this library's own
+                deflate, checked against the oracle) replicated to --inflate-streams, MB/s
+                out with its own roofline (k_inflate) and CPU baseline.
+  levels_64k    BASELINE config 3: 1 GiB of 64 KiB random / zero / text buffers at
+                levels 1, 6 and 9.
 """
 from __future__ import annotations
 
@@ -75,6 +83,169 @@ def cpu_baseline(level: int, seconds_budget: float = 20.0):
                       f"{level}, one codec instance per thread, {dt:.1f} s wall"}
 
 
+def cpu_inflate_baseline(streams, outs, seconds_budget: float = 10.0):
+    """Time the CPU decoder on the host cores over the distinct gzip members (bounded sample)."""
+    from concurrent.futures import ThreadPoolExecutor
+    from oracle.oracle_py import Oracle, Reference
+
+    cores = os.cpu_count() or 1
+    try:
+        cores = len(os.sched_getaffinity(0))
+    except Exception:
+        pass
+    cores = max(1, min(cores, int(os.environ.get("ZSC_BENCH_CPU_THREADS", "16"))))
+    kind = "reference" if Reference.available() else "port"
+
+    def worker(idx: int):
+        codec = Reference() if kind == "reference" else Oracle()
+        done = 0
+        t_end = time.perf_counter() + seconds_budget
+        k = idx
+        while time.perf_counter() < t_end:
+            s, o = streams[k % len(streams)], outs[k % len(streams)]
+            res = codec.uncompress(s, len(o), window_bits=31)
+            assert res[0] == 0 and len(res[1]) == len(o)
+            done += len(o)
+            k += cores
+        return done
+
+    t0 = time.perf_counter()
+    with ThreadPoolExecutor(max_workers=cores) as ex:
+        total = sum(ex.map(worker, range(cores)))
+    dt = time.perf_counter() - t0
+    return {"value": round(total / dt / 1e6, 2), "unit": "MB/s out", "cores": cores, "kind": kind,
+            "sample": f"{total / 1e6:.0f} MB of output from the {len(streams)} distinct gzip members, "
+                      f"zsc_uncompress_gzip semantics, one codec instance per thread, {dt:.1f} s wall"}
+
+
+def bench_inflate(dev, stream, nstreams: int, distinct: int, fence):
+    """BASELINE config 4: inflate-only over gzip members of 4-64 KiB."""
+    import torch
+    import zsc_amd
+    from zsc_amd import corpus
+    from oracle.oracle_py import Oracle
+
+    distinct = max(1, min(distinct, nstreams))
+    st = corpus.Stream(4242, 3)
+    sizes = [4096 + int(x) for x in st.below(distinct, 65536 - 4096 + 1)]
+    kinds = ("text", "text", "token", "table")
+    bufs = [corpus.make_buffer(kinds[i % 4], sizes[i], 7000 + i) for i in range(distinct)]
+    # the members: this library's own deflate (gzip wrapper), every one checked against the oracle
+    rc, members, stats = zsc_amd.compress_batch(bufs, level=6, window_bits=31)
+    if rc != 0 or any(x != 0 for x in stats):
+        raise SystemExit("inflate bench: making the gzip members failed")
+    oracle = Oracle()
+    nchk = min(distinct, int(os.environ.get("ZSC_BENCH_INFLATE_CHECK", "256")))
+    for i in range(nchk):
+        if oracle.compress(bufs[i], 6, window_bits=31)[1] != members[i]:
+            raise SystemExit(f"inflate bench: gzip member {i} differs from the oracle")
+    slens = [len(m) for m in members]
+    reps = (nstreams + distinct - 1) // distinct
+    all_slens = (slens * reps)[:nstreams]
+    all_caps = (sizes * reps)[:nstreams]
+    ip = zsc_amd.InflatePlan(all_slens, all_caps, window_bits=31)
+    # one period of the source layout on the host, replicated on the device
+    per_src = ip.src_offsets[distinct] if nstreams > distinct else ip.src_bytes - 64
+    per_dst = ip.dst_offsets[distinct] if nstreams > distinct else ip.dst_bytes - 64
+    host = torch.zeros(per_src, dtype=torch.uint8)
+    for off, m in zip(ip.src_offsets, members):
+        host[off:off + len(m)] = torch.frombuffer(bytearray(m), dtype=torch.uint8)
+    d_per = host.to(dev)
+    d_src = torch.zeros(ip.src_bytes, dtype=torch.uint8, device=dev)
+    d_src[:ip.src_bytes - 64] = d_per.repeat(reps)[:ip.src_bytes - 64]
+    d_dst = torch.empty(ip.dst_bytes, dtype=torch.uint8, device=dev)
+    ip.run(d_src.data_ptr(), d_dst.data_ptr(), stream)
+    ip.results()
+    fence()
+    t1 = time.perf_counter()
+    steps = 2
+    kms = 0.0
+    for _ in range(steps):
+        ip.run(d_src.data_ptr(), d_dst.data_ptr(), stream)
+        kms += ip.results()[3]
+    fence()
+    wall = (time.perf_counter() - t1) / steps
+    kms /= steps
+    olens, used, istat, _ = ip.results()
+    ok = all(x == 0 for x in istat) and olens == all_caps and used == all_slens
+    # every distinct member's bytes against its source; every replica against the first copy
+    first = d_dst[:per_dst].cpu()
+    for i in range(distinct):
+        got = bytes(first[ip.dst_offsets[i]:ip.dst_offsets[i] + sizes[i]].numpy())
+        ok = ok and got == bufs[i]
+    mask = torch.zeros(per_dst, dtype=torch.bool)
+    for i in range(distinct):
+        mask[ip.dst_offsets[i]:ip.dst_offsets[i] + sizes[i]] = True
+    d_mask = mask.to(dev)
+    full = (ip.dst_bytes - 64) // per_dst
+    rows = d_dst[:full * per_dst].view(full, per_dst)
+    ok = ok and bool((rows[:, d_mask] == rows[0, d_mask]).all())
+    out_bytes, in_bytes = sum(all_caps), sum(all_slens)
+    achieved = (out_bytes + in_bytes) / (kms * 1e-3) / 1e9 if kms > 0 else 0.0
+    info = {"metric": "inflate uncompressed MB/s out, gzip members of 4-64 KiB (BASELINE config 4)",
+            "value": round(out_bytes / wall / 1e6, 2), "unit": "MB/s", "ms_per_step": round(wall * 1e3, 3),
+            "streams": nstreams, "distinct_members": distinct, "output_bytes": out_bytes,
+            "compressed_bytes": in_bytes, "all_ok": bool(ok),
+            "roofline": {"bound": "hbm", "kernel": "k_inflate", "achieved": round(achieved, 3),
+                         "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 6),
+                         "kernel_ms": round(kms, 3), "algorithmic_bytes_per_launch": out_bytes + in_bytes,
+                         "traffic": None},
+            "note": "zsc_uncompress_gzip semantics (header, CRC-32 and ISIZE checked), one wavefront per "
+                    "member, members and outputs resident in HBM; all outputs compared with their sources"}
+    ip.close()
+    del d_src, d_dst, rows
+    return info, members, bufs
+
+
+def bench_levels_64k(dev, stream, count: int, fence):
+    """BASELINE config 3: count x 64 KiB (random / zero / text) at levels 1, 6, 9."""
+    import torch
+    import zsc_amd
+    from zsc_amd import corpus
+    from oracle.oracle_py import Oracle
+
+    distinct = min(count, 96)
+    bufs = corpus.mix64k(distinct, 5)
+    oracle = Oracle()
+    out = {}
+    for level in (1, 6, 9):
+        plan = zsc_amd.DeflatePlan([65536] * count, level=level)
+        per = plan.in_offsets[distinct] if count > distinct else plan.in_bytes - 64
+        host = torch.zeros(per, dtype=torch.uint8)
+        for off, b in zip(plan.in_offsets, bufs):
+            host[off:off + len(b)] = torch.frombuffer(bytearray(b), dtype=torch.uint8)
+        reps = (count + distinct - 1) // distinct
+        d_in = torch.zeros(plan.in_bytes, dtype=torch.uint8, device=dev)
+        d_in[:plan.in_bytes - 64] = host.to(dev).repeat(reps)[:plan.in_bytes - 64]
+        d_out = torch.empty(plan.out_bytes, dtype=torch.uint8, device=dev)
+        plan.run(d_in.data_ptr(), d_out.data_ptr(), stream)
+        plan.results()
+        fence()
+        plan.profile(True)
+        t1 = time.perf_counter()
+        steps = 2
+        for _ in range(steps):
+            plan.run(d_in.data_ptr(), d_out.data_ptr(), stream)
+        fence()
+        wall = (time.perf_counter() - t1) / steps
+        lens, stats = plan.results()
+        kt = plan.kernel_times_ms()
+        ok = all(x == 0 for x in stats)
+        head = d_out[:plan.out_offsets[distinct - 1] + plan.out_caps[distinct - 1]].cpu()
+        for k in range(distinct):  # every distinct buffer against the oracle
+            got = bytes(head[plan.out_offsets[k]:plan.out_offsets[k] + lens[k]].numpy())
+            ok = ok and got == oracle.compress(bufs[k], level)[1]
+        ok = ok and all(lens[i] == lens[i % distinct] for i in range(count))
+        out[f"L{level}"] = {"MB_per_s_in": round(65536 * count / wall / 1e6, 2), "ms_per_step": round(wall * 1e3, 3),
+                            "compressed_bytes": sum(lens), "all_ok": bool(ok),
+                            "kernel_ms": {k: round(v, 3) for k, v in kt.items()}}
+        plan.close()
+        del d_in, d_out
+    return {"metric": "deflate uncompressed MB/s in, 64 KiB random / zero / text buffers (BASELINE config 3)",
+            "buffers": count, "input_bytes": 65536 * count, "levels": out,
+            "note": f"{distinct} distinct buffers replicated; every distinct stream compared with the oracle"}
+
+
 def main() -> None:
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -84,7 +255,13 @@ def main() -> None:
     ap.add_argument("--seeds", type=int, default=8, help="distinct seeds among the copies")
     ap.add_argument("--level", type=int, default=6)
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--verify", type=int, default=1, help="buffers per rank checked against the oracle")
+    ap.add_argument("--verify", type=int, default=-1,
+                    help="distinct buffers per rank checked against the oracle (-1: all of them)")
+    ap.add_argument("--inflate-streams", type=int, default=1048576,
+                    help="gzip members of the inflate section (BASELINE config 4; 0: skip)")
+    ap.add_argument("--inflate-distinct", type=int, default=2048, help="distinct gzip members among them")
+    ap.add_argument("--levels-64k", type=int, default=16384,
+                    help="64 KiB buffers of the level 1/6/9 section (BASELINE config 3; 0: skip)")
     ap.add_argument("--with-inflate", action="store_true",
                     help="also time the inflate kernel on the produced streams (extra field)")
     ap.add_argument("--max-block-len", type=int, default=0,
@@ -177,14 +354,33 @@ def main() -> None:
     from oracle.oracle_py import Oracle
     oracle = Oracle()
     out_host = None
-    for i in range(min(args.verify, len(period_bufs))):
-        k = (7 * i + 2) % len(period_bufs)
+    nver = len(period_bufs) if args.verify < 0 else min(args.verify, len(period_bufs))
+    for i in range(nver):
+        k = i if nver == len(period_bufs) else (7 * i + 2) % len(period_bufs)
         if out_host is None:
             out_host = d_out[:plan.out_offsets[len(period_bufs) - 1] + plan.out_caps[len(period_bufs) - 1]].cpu()
         got = bytes(out_host[plan.out_offsets[k]:plan.out_offsets[k] + lens[k]].numpy())
         rc, want, _ = oracle.compress(period_bufs[k], args.level)
         if rc != 0 or got != want:
             raise SystemExit(f"rank {rank}: buffer {k} differs from the oracle")
+    # the other copies: same length as, and on the device byte for byte equal to, the first copy
+    nper = len(period_bufs)
+    replicas_ok = all(lens[i] == lens[i % nper] for i in range(len(lens)))
+    if len(my_lens) > nper:
+        per_out = plan.out_offsets[nper]
+        mask = torch.zeros(per_out, dtype=torch.bool)
+        for k in range(nper):
+            mask[plan.out_offsets[k]:plan.out_offsets[k] + lens[k]] = True
+        d_mask = mask.to(dev)
+        full = len(my_lens) // nper
+        rows = d_out[:full * per_out].view(full, per_out)
+        for r0 in range(0, full, 64):  # in slices, to bound the temporary
+            replicas_ok = replicas_ok and bool((rows[r0:r0 + 64][:, d_mask] == rows[0][d_mask]).all())
+        del rows, d_mask
+    if not replicas_ok:
+        raise SystemExit(f"rank {rank}: a replica's stream differs from its first copy")
+    checked = {"distinct_buffers_vs_oracle": nver, "of": nper, "replicas_equal_on_device": bool(replicas_ok),
+               "buffers": len(my_lens)}
 
     # ---- inflate of the streams just produced (reported beside the headline, not part of it)
     inflate_info = None
@@ -269,8 +465,11 @@ def main() -> None:
                          "algorithmic_bytes_per_launch": alg_bytes,
                          "kernel_ms": {k: round(v, 3) for k, v in ktimes.items()}},
             "scratch_bytes": plan.scratch_bytes,
+            "checked": checked,
             "device": zsc_amd.device_info(),
         }
+        line["roofline"]["limited_by"] = ("instruction issue, not HBM: the parse is serial control flow per "
+                                          "position (DESIGN.md section 5)")
         # HBM traffic of the dominant kernel from rocprofv3 --pmc passes (profiles/pmc_traffic.json),
         # scaled by input bytes when the PMC run used a smaller batch of the same workload
         try:
@@ -282,13 +481,26 @@ def main() -> None:
         except Exception:
             pass
         if inflate_info:
-            line["inflate"] = inflate_info
+            line["inflate_of_these_streams"] = inflate_info
         if sections_info:
             line["sections"] = sections_info
         if not args.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline(args.level)
-        print(json.dumps(line), flush=True)
     plan.close()
+    del d_in, d_out
+    if rank == 0 and world == 1:
+        # the rest of BASELINE's metric, beside the headline (one GPU only: these are not sharded)
+        torch.cuda.empty_cache()
+        if args.inflate_streams > 0:
+            info, members, outs = bench_inflate(dev, stream, args.inflate_streams, args.inflate_distinct, fence)
+            if not args.no_cpu_baseline:
+                info["cpu_baseline"] = cpu_inflate_baseline(members, outs)
+            line["inflate"] = info
+            torch.cuda.empty_cache()
+        if args.levels_64k > 0:
+            line["levels_64k"] = bench_levels_64k(dev, stream, args.levels_64k, fence)
+    if rank == 0:
+        print(json.dumps(line), flush=True)
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()

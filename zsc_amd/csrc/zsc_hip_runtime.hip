@@ -647,6 +647,7 @@ const ZdLevel kLevels[10] = {
 
 std::once_flag g_init_once;
 int g_init_status = Z_STREAM_ERROR;
+int g_device = -1; /* the device this process's plans, scratch and kernels live on */
 char g_device_info[256] = "uninitialised";
 
 #define HIP_TRY(expr, fail)                                                              \
@@ -669,8 +670,14 @@ void do_init(int ordinal)
         return;
     }
     if (ordinal < 0) {
+        /* one process per GPU: LOCAL_RANK names it; without it, the device the calling thread
+         * works on already (never silently device 0 under somebody else's feet) */
         const char *lr = getenv("LOCAL_RANK");
-        ordinal = lr ? atoi(lr) % count : 0;
+        int cur = 0;
+        if (lr)
+            ordinal = atoi(lr) % count;
+        else
+            ordinal = hipGetDevice(&cur) == hipSuccess ? cur : 0;
     }
     if (hipSetDevice(ordinal) != hipSuccess) {
         ZSC_WARN1("zsc_hip: cannot select device %d.", ordinal);
@@ -693,8 +700,33 @@ void do_init(int ordinal)
     g_dev_cache_cap = prop.totalGlobalMem / 4;
     if (const char *e = getenv("ZSC_HIP_CACHE_MB"))
         g_dev_cache_cap = (size_t)atoll(e) << 20;
+    g_device = ordinal;
     g_init_status = Z_OK;
 }
+
+/* HIP's current device is a property of the calling THREAD.  Every entry point that touches
+ * the device runs inside one of these: it selects the library's device for the call and puts
+ * the thread's own choice back afterwards, so a caller (or another library) that works on a
+ * different GPU is not disturbed, and a second thread does not launch on its default device
+ * against memory that lives on ours. */
+void ensure_init();
+struct DeviceScope {
+    int prev = -1;
+    bool changed = false;
+    DeviceScope()
+    {
+        ensure_init();
+        if (g_device >= 0 && hipGetDevice(&prev) == hipSuccess && prev != g_device)
+            changed = hipSetDevice(g_device) == hipSuccess;
+    }
+    ~DeviceScope()
+    {
+        if (changed)
+            (void)hipSetDevice(prev);
+    }
+    DeviceScope(const DeviceScope &) = delete;
+    DeviceScope &operator=(const DeviceScope &) = delete;
+};
 
 /* Freed device blocks, kept for the next plan.  The one-shot entry points (zsc_compress ...)
  * build and drop a plan per call and the sections path one per round; hipMalloc / hipFree cost
@@ -780,6 +812,9 @@ struct DevBuf {
     }
 };
 
+/* the longest buffer one plan entry may be: deflateBound of it stays below 2^29 bytes = 2^32 bits */
+#define ZSC_HIP_MAX_BUFFER 0x1ff00000u
+
 /* a group of buffers that shares one set of scratch arrays */
 struct SubBatch {
     uint32_t first = 0, count = 0; /* buffers [first, first+count) of the plan */
@@ -821,14 +856,36 @@ struct zsc_hip_deflate_plan {
     uint64_t scratch_bytes = 0;
 };
 
+namespace {
+void ensure_init()
+{
+    int before = -1;
+    (void)hipGetDevice(&before);
+    std::call_once(g_init_once, do_init, -1);
+    if (before >= 0 && getenv("LOCAL_RANK") == nullptr)
+        (void)hipSetDevice(before); /* (do_init selects the device it adopts; a no-op here) */
+}
+} // namespace
+
 extern "C" I32 zsc_hip_init(I32 device_ordinal)
 {
+    int before = -1;
+    (void)hipGetDevice(&before);
     std::call_once(g_init_once, do_init, (int)device_ordinal);
+    if (g_init_status == Z_OK && device_ordinal >= 0 && device_ordinal != g_device) {
+        ZSC_WARN2("zsc_hip: already initialised on device %d, cannot move to device %d.", g_device,
+                  (int)device_ordinal);
+        return Z_STREAM_ERROR;
+    }
+    /* the calling thread keeps the device it had unless it asked for this one by number */
+    if (device_ordinal < 0 && before >= 0 && getenv("LOCAL_RANK") == nullptr)
+        (void)hipSetDevice(before);
     return g_init_status;
 }
 
 extern "C" void zsc_hip_release_cached_memory(void)
 {
+    DeviceScope scope;
     g_dev_cache.trim();
 }
 
@@ -928,6 +985,7 @@ static ZlibReturn plan_create(zsc_hip_deflate_plan **plan_out, U32 count, const 
                               const U32 *out_caps, I32 level, I32 window_bits, I32 mem_level,
                               ZlibStrategy strategy, const PlanRuns *runs)
 {
+    DeviceScope scope;
     ZSC_ASSERT(plan_out != Z_NULL);
     *plan_out = nullptr;
     if (zsc_hip_init(-1) != Z_OK)
@@ -967,6 +1025,14 @@ static ZlibReturn plan_create(zsc_hip_deflate_plan **plan_out, U32 count, const 
         uint64_t bytes = 0;
         while (i < count && (sb.count == 0 || bytes + source_lens[i] <= sub_limit)) {
             const uint32_t n = source_lens[i];
+            if (n >= ZSC_HIP_MAX_BUFFER) {
+                /* bit positions inside one stream are 32-bit (ZdBlockPlan.bit_off, the layout and
+                 * emit kernels): a stream must stay below 2^32 bits */
+                ZSC_WARN2("zsc_hip: buffer %u has %u bytes; one buffer (or one run of sections) is limited "
+                          "to 535 822 335 bytes.", i, n);
+                delete pl;
+                return Z_MEM_ERROR;
+            }
             if (in_offsets[i] & 15u || out_offsets[i] & 15u) {
                 ZSC_WARN1("zsc_hip: buffer %u is not 16-byte aligned in the batch.", i);
                 delete pl;
@@ -978,7 +1044,7 @@ static ZlibReturn plan_create(zsc_hip_deflate_plan **plan_out, U32 count, const 
             b.out_off = out_offsets[i];
             b.in_len = n;
             b.out_cap = out_caps[i];
-            b.ntiles = n == 0 ? 1u : (n + ZD_TILE - 1) / ZD_TILE;
+            b.ntiles = n == 0 ? 1u : (uint32_t)(((uint64_t)n + ZD_TILE - 1) / ZD_TILE);
             b.tile0 = sb.ntiles;
             b.max_blocks = n / ((1u << (mem_level + 6)) - 1u) + 2;
             if (runs) {
@@ -1170,6 +1236,7 @@ extern "C" void zsc_hip_deflate_plan_profile(zsc_hip_deflate_plan *plan, I32 ena
 extern "C" ZlibReturn zsc_hip_deflate_plan_run(zsc_hip_deflate_plan *pl, const void *d_input,
                                                void *d_output, void *hip_stream)
 {
+    DeviceScope scope;
     ZSC_ASSERT(pl != Z_NULL);
     ZSC_ASSERT(d_input != Z_NULL);
     ZSC_ASSERT(d_output != Z_NULL);
@@ -1297,6 +1364,7 @@ extern "C" ZlibReturn zsc_hip_deflate_plan_run(zsc_hip_deflate_plan *pl, const v
 extern "C" ZlibReturn zsc_hip_deflate_plan_results(zsc_hip_deflate_plan *pl, U32 *dest_lens,
                                                    I32 *statuses)
 {
+    DeviceScope scope;
     ZSC_ASSERT(pl != Z_NULL);
     HIP_TRY(hipStreamSynchronize(pl->last_stream), return Z_STREAM_ERROR);
     std::vector<ZdResult> res(pl->count);
@@ -1338,6 +1406,7 @@ extern "C" ZlibReturn zsc_hip_deflate_plan_results(zsc_hip_deflate_plan *pl, U32
 
 extern "C" ZlibReturn zsc_hip_deflate_plan_times(zsc_hip_deflate_plan *pl, float *ms_out)
 {
+    DeviceScope scope;
     ZSC_ASSERT(pl != Z_NULL);
     ZSC_ASSERT(ms_out != Z_NULL);
     for (int k = 0; k < ZSC_HIP_NKERNELS; k++)
@@ -1357,6 +1426,7 @@ extern "C" U32 zsc_hip_deflate_plan_sub_batches(const zsc_hip_deflate_plan *pl)
 
 extern "C" void zsc_hip_deflate_plan_destroy(zsc_hip_deflate_plan *pl)
 {
+    DeviceScope scope;
     if (!pl)
         return;
     (void)hipStreamSynchronize(pl->last_stream); /* the blocks go back to the cache, not to hipFree */
@@ -1577,6 +1647,7 @@ extern "C" ZlibReturn zsc_hip_store_batch(U32 count, const U8 *const *sources, c
                                           U32 *dest_lens, I32 *statuses, I32 window_bits,
                                           I32 mem_level, U32 gzip_header_len)
 {
+    DeviceScope scope;
     ZSC_ASSERT(sources != Z_NULL);
     ZSC_ASSERT(source_lens != Z_NULL);
     ZSC_ASSERT(max_block_lens != Z_NULL);
@@ -1865,6 +1936,7 @@ static ZlibReturn sections_on_device(U32 count, const uint8_t *d_src, const uint
                                      U32 *dest_lens, I32 *statuses, I32 level, I32 window_bits,
                                      I32 mem_level, ZlibStrategy strategy, U32 gzip_header_len)
 {
+    DeviceScope scope;
     if (zsc_hip_init(-1) != Z_OK)
         return Z_STREAM_ERROR;
     int wrap = 1, wbits = 15;
@@ -2019,6 +2091,7 @@ extern "C" ZlibReturn zsc_hip_compress_sections_device(U32 count, const void *d_
                                                        U32 *dest_lens, I32 *statuses, I32 level,
                                                        I32 window_bits, I32 mem_level, ZlibStrategy strategy)
 {
+    DeviceScope scope;
     ZSC_ASSERT(d_input != Z_NULL);
     ZSC_ASSERT(in_offsets != Z_NULL);
     ZSC_ASSERT(source_lens != Z_NULL);
@@ -2040,6 +2113,7 @@ extern "C" ZlibReturn zsc_hip_compress_sections_batch(U32 count, const U8 *const
                                                       I32 level, I32 window_bits, I32 mem_level,
                                                       ZlibStrategy strategy, U32 gzip_header_len)
 {
+    DeviceScope scope;
     ZSC_ASSERT(sources != Z_NULL);
     ZSC_ASSERT(source_lens != Z_NULL);
     ZSC_ASSERT(max_block_lens != Z_NULL);
@@ -2097,6 +2171,7 @@ extern "C" ZlibReturn zsc_hip_compress_batch(U32 count, const U8 *const *sources
                                              I32 window_bits, I32 mem_level,
                                              ZlibStrategy strategy)
 {
+    DeviceScope scope;
     ZSC_ASSERT(sources != Z_NULL);
     ZSC_ASSERT(source_lens != Z_NULL);
     ZSC_ASSERT(dests != Z_NULL);
@@ -2187,6 +2262,7 @@ extern "C" ZlibReturn zsc_hip_inflate_plan_create(zsc_hip_inflate_plan **plan_ou
                                                   const U32 *dest_caps,
                                                   const uint64_t *dst_offsets, I32 window_bits)
 {
+    DeviceScope scope;
     ZSC_ASSERT(plan_out != Z_NULL);
     *plan_out = nullptr;
     if (zsc_hip_init(-1) != Z_OK)
@@ -2233,6 +2309,7 @@ extern "C" ZlibReturn zsc_hip_inflate_plan_create(zsc_hip_inflate_plan **plan_ou
 extern "C" ZlibReturn zsc_hip_inflate_plan_run(zsc_hip_inflate_plan *pl, const void *d_src,
                                                void *d_dst, void *hip_stream)
 {
+    DeviceScope scope;
     ZSC_ASSERT(pl != Z_NULL);
     hipStream_t st = (hipStream_t)hip_stream;
     pl->last_stream = st;
@@ -2257,6 +2334,7 @@ extern "C" ZlibReturn zsc_hip_inflate_plan_run(zsc_hip_inflate_plan *pl, const v
 extern "C" ZlibReturn zsc_hip_inflate_plan_results(zsc_hip_inflate_plan *pl, U32 *dest_lens,
                                                    U32 *consumed, I32 *statuses, float *kernel_ms)
 {
+    DeviceScope scope;
     ZSC_ASSERT(pl != Z_NULL);
     HIP_TRY(hipStreamSynchronize(pl->last_stream), return Z_STREAM_ERROR);
     /* streams that hit a data error and found a flush marker behind it (inflateSync) are
@@ -2300,6 +2378,7 @@ extern "C" ZlibReturn zsc_hip_inflate_plan_results(zsc_hip_inflate_plan *pl, U32
 
 extern "C" void zsc_hip_inflate_plan_destroy(zsc_hip_inflate_plan *pl)
 {
+    DeviceScope scope;
     if (!pl)
         return;
     (void)hipStreamSynchronize(pl->last_stream);
@@ -2320,6 +2399,7 @@ extern "C" ZlibReturn zsc_hip_uncompress_batch(U32 count, const U8 *const *sourc
                                                U32 *source_lens, U8 *const *dests,
                                                U32 *dest_lens, I32 *statuses, I32 window_bits)
 {
+    DeviceScope scope;
     ZSC_ASSERT(sources != Z_NULL);
     ZSC_ASSERT(source_lens != Z_NULL);
     ZSC_ASSERT(dests != Z_NULL);
