@@ -36,7 +36,9 @@ SIZES = [0, 1, 2, 3, 4, 9, 100, 258, 259, 262, 4096, 16385, 32768, 36865, 65275,
 
 
 def test_checksum_kernels(emu, oracle):
-    for n in (0, 1, 15, 16, 17, 1023, 1024, 1025, 5552, 70001):
+    # lengths around the CRC kernel's segment sizes (64 lanes x a power of two) and Adler's 5552
+    for n in (0, 1, 15, 16, 17, 1008, 1023, 1024, 1025, 1040, 2048, 2049, 4097, 5552, 65535, 65536, 65537, 70001,
+              131073):
         d = corpus.make_buffer("random", n, n)
         assert emu.emu_adler32(d, n) == oracle.adler32(d)
         assert emu.emu_crc32(d, n) == oracle.crc32(d)

@@ -46,7 +46,7 @@ typedef struct {
     InfCode lit, dist, cl;
     uint16_t lens[320];
     uint8_t stage[INF_STAGE + 320]; /* output not yet stored: [flushed, pos) */
-    CkLds ck;
+    CkLdsT<1> ck; /* the byte-loop tables: the decoder wants its LDS for waves, not for tables */
 } InfLds;
 
 /* where decoding goes on after an inflateSync: the stream is inflated again from there */
@@ -518,7 +518,7 @@ DEV int inflate_stream(const InfJob &job, InfLds *lds, InfResult *res, InfResume
                 uint32_t got;
                 INF_NEED(16);
                 INF_TAKE(got, 16);
-                if ((wrap & 4) && got != (ck_crc32(src, upto, &lds->ck) & 0xffffu))
+                if ((wrap & 4) && got != (ck_crc32_t<1>(src, upto, &lds->ck) & 0xffffu))
                     INF_BADX(16, 16); /* :944-950 */
             }
         } else {
@@ -787,7 +787,7 @@ DEV int inflate_stream(const InfJob &job, InfLds *lds, InfResult *res, InfResume
 #ifndef ZSC_WAVE_EMU
                 __threadfence_block();
 #endif
-                const uint32_t want = gzip ? ck_crc32(dst, pos, &lds->ck) : ck_adler32(dst, pos);
+                const uint32_t want = gzip ? ck_crc32_t<1>(dst, pos, &lds->ck) : ck_adler32(dst, pos);
                 const uint32_t got = gzip ? v : ((v >> 24) | ((v >> 8) & 0xff00u) | ((v & 0xff00u) << 8) | (v << 24));
                 if (got != want)
                     INF_BADX(32, 32); /* :1333-1339 */
