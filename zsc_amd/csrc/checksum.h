@@ -98,7 +98,7 @@ DEV uint32_t ck_x2n(uint32_t j)
  * :517-525, for callers that are short of LDS).  The 64 remainders are then combined as
  * polynomials:  r(A || B) = r(A) * x^(8 |B|) + r(B)  mod P.  With all segments but the last
  * S bytes long the factors are powers of X = x^(8 S) = x^(2^k), a constant from a table:
- * six log-steps over the lanes, each one multiplication per lane (ck_mulmod, all lanes in
+ * log-steps over the lanes, each one multiplication per lane (ck_mulmod, all lanes in
  * step), then one multiplication by x^(8 len(last segment)) -- itself a product over the
  * set bits of the length, reduced over the lanes the same way.  The preset register is lane
  * 0's starting value. */
@@ -112,7 +112,6 @@ typedef CkLdsT<4> CkLds;
 template <int NT>
 DEV uint32_t ck_crc32_t(const uint8_t *in, uint32_t n, CkLdsT<NT> *lds)
 {
-    static_assert(WAVE == 64, "the combining steps are written for 64 lanes");
     for (int i = 0; i < 256; i += WAVE) {
         FOR_LANES
         {
@@ -182,7 +181,7 @@ DEV uint32_t ck_crc32_t(const uint8_t *in, uint32_t n, CkLdsT<NT> *lds)
     }
     WAVE_SYNC();
     /* log-steps: the value at the right end of a block of 2d lanes becomes left * X^d + right */
-    for (uint32_t m = 0; m < 6u; m++) {
+    for (uint32_t m = 0; (1u << m) < WAVE; m++) {
         const uint32_t d = 1u << m;
         const uint32_t xd = ck_x2n(3u + k + m); /* X^d = x^(8 S d) */
         FOR_LANES { lds->x[LANE] = LV(v); }
@@ -201,9 +200,11 @@ DEV uint32_t ck_crc32_t(const uint8_t *in, uint32_t n, CkLdsT<NT> *lds)
     LANEVAR(uint32_t, f);
     FOR_LANES
     {
-        const uint32_t j = (uint32_t)LANE;
         const uint64_t bits = (uint64_t)len_last * 8u;
-        LV(f) = (j < 40u && ((bits >> j) & 1ull)) ? ck_x2n(j) : 0x80000000u;
+        uint32_t prod = 0x80000000u; /* x^0 */
+        for (uint32_t j = (uint32_t)LANE; j < 40u; j += WAVE)
+            prod = ((bits >> j) & 1ull) ? ck_mulmod(prod, ck_x2n(j)) : prod;
+        LV(f) = prod;
     }
     for (uint32_t d = 1; d < WAVE; d <<= 1) {
         FOR_LANES { lds->x[LANE] = LV(f); }

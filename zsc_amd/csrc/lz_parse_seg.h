@@ -50,6 +50,9 @@
 #ifndef SG_SPAN
 #define SG_SPAN 8192u               /* positions per super-step */
 #endif
+#ifndef SG_MIN_WAVES
+#define SG_MIN_WAVES 6 /* waves per SIMD the register allocation aims at (three workgroups per CU) */
+#endif
 #define SG_NS (SG_SPAN / SG_G)      /* segments per super-step, handed to the waves by a work queue */
 #define SG_OV 512u                  /* how far past its segment a parser looks for a hand-over */
 #define SG_TRACE SG_G               /* positions a segment records (its own) */
@@ -176,14 +179,14 @@ DEV void sg_phase_begin(const LzJob &job, SgLds *lds, int w)
  * them at once with a popcount. */
 
 /* four bytes of the window as a wave-uniform value */
-#define SG_PEEK32(pos, out) ((out) = UNI(lds_u32(lds->ring, lz_ridx<L>(st, (pos)))))
+#define SG_PEEK32(pos, out) ((out) = GUNI(lds_u32(lds->ring, lz_ridx<L>(st, (pos)))))
 
 /* entries of candidates 64*B .. 64*B+63; lanes past the end of the chain read entry 0 of
  * the tile (a valid address) and are masked later -- cheaper than predicating the load */
 #define SG_LOAD(E, B)                                                                         \
-    FOR_LANES                                                                                 \
+    FOR_GLANES                                                                                 \
     {                                                                                         \
-        const uint32_t _v = (B)*64u + (uint32_t)LANE;                                         \
+        const uint32_t _v = (B)*GRP + (uint32_t)GLANE;                                         \
         int32_t _i = _v < nA ? hiA - (int32_t)_v : hiB - (int32_t)(_v - nA) - (int32_t)ZD_TILE; \
         _i = _v < total ? _i : 0;                                                             \
         LV(E) = runA[_i];                                                                     \
@@ -195,31 +198,58 @@ DEV void sg_phase_begin(const LzJob &job, SgLds *lds, int w)
         SG_COUNT(1, 1);                                                                       \
         if (pv_at != p) {                                                                     \
             pv_at = p;                                                                        \
-            FOR_LANES { LV(pv) = lds_u32(lds->ring, lz_ridx<L>(st, p + 4u * (uint32_t)LANE)); } \
+            FOR_GLANES { LV(pv) = lds_u32(lds->ring, lz_ridx<L>(st, p + 4u * (uint32_t)GLANE)); } \
         }                                                                                     \
-        LANEVAR(uint32_t, _diff);                                                             \
-        LANEVAR(int, _differs);                                                               \
-        FOR_LANES                                                                             \
-        {                                                                                     \
-            LV(_diff) = lds_u32(lds->ring, lz_ridx<L>(st, (QJ) + 4u * (uint32_t)LANE)) ^ LV(pv); \
-            LV(_differs) = LV(_diff) != 0;                                                    \
-        }                                                                                     \
-        const uint64_t _dm = BALLOT(_differs);                                                \
-        if (_dm != 0) {                                                                       \
-            const int _f = CTZ64(_dm);                                                        \
-            (LEN) = 4u * (uint32_t)_f + ((uint32_t)CTZ32(READLANE(_diff, _f)) >> 3);          \
-        } else {                                                                              \
-            (LEN) = 256;                                                                      \
-            if (cap > 256 && UNI(lds->ring[lz_ridx<L>(st, (QJ) + 256)]) ==                    \
-                                 UNI(lds->ring[lz_ridx<L>(st, p + 256)])) {                   \
-                (LEN) = 257;                                                                  \
-                if (cap > 257 && UNI(lds->ring[lz_ridx<L>(st, (QJ) + 257)]) ==                \
-                                     UNI(lds->ring[lz_ridx<L>(st, p + 257)]))                 \
-                    (LEN) = 258;                                                              \
+        (LEN) = cap;                                                                          \
+        /* 4 GRP bytes per step (the first one against the string at p held in registers); what a \
+         * step reads past cap is cut off below */                                            \
+        for (uint32_t _o = 0; _o < cap; _o += 4u * GRP) {                                     \
+            LANEVAR(uint32_t, _diff);                                                         \
+            LANEVAR(int, _differs);                                                           \
+            FOR_GLANES                                                                        \
+            {                                                                                 \
+                const uint32_t _pw = _o == 0u ? LV(pv)                                        \
+                                              : lds_u32(lds->ring, lz_ridx<L>(st, p + _o + 4u * (uint32_t)GLANE)); \
+                LV(_diff) = lds_u32(lds->ring, lz_ridx<L>(st, (QJ) + _o + 4u * (uint32_t)GLANE)) ^ _pw; \
+                LV(_differs) = LV(_diff) != 0;                                                \
+            }                                                                                 \
+            const uint64_t _dm = GBALLOT(_differs);                                           \
+            if (_dm != 0) {                                                                   \
+                const int _f = CTZ64(_dm);                                                    \
+                (LEN) = _o + 4u * (uint32_t)_f + ((uint32_t)CTZ32(GREADLANE(_diff, _f)) >> 3); \
+                break;                                                                        \
             }                                                                                 \
         }                                                                                     \
         if ((LEN) > cap)                                                                      \
             (LEN) = cap;                                                                      \
+    } while (0)
+
+/* LZ_HEAD_BLOCKED (lz_parse.h) for a group: is there a position between Q and P whose hash under
+ * the reference's hash function (another mem_level) equals P's? */
+#define SG_HEAD_BLOCKED(Q, P, MEMB, blocked)                                                  \
+    do {                                                                                      \
+        (blocked) = 0;                                                                        \
+        const uint32_t _hs = (job.cfg.hbits + 2u) / 3u, _hm = (1u << job.cfg.hbits) - 1u;     \
+        const uint32_t _wp = GUNI(lds_u32(lds->ring, lz_ridx<L>(st, (P))));                   \
+        const uint32_t _hp = (((_wp & 0xffu) << (2u * _hs)) ^ (((_wp >> 8) & 0xffu) << _hs) ^ \
+                              ((_wp >> 16) & 0xffu)) & _hm;                                   \
+        for (uint32_t _x0 = (Q) + 1u; _x0 < (P) && !(blocked); _x0 += GRP) {                  \
+            LANEVAR(int, _same);                                                              \
+            FOR_GLANES                                                                        \
+            {                                                                                 \
+                const uint32_t _x = _x0 + (uint32_t)GLANE;                                    \
+                int _s = 0;                                                                   \
+                if (_x < (P)) {                                                               \
+                    const uint32_t _w = lds_u32(lds->ring, lz_ridx<L>(st, _x));               \
+                    const uint32_t _h = (((_w & 0xffu) << (2u * _hs)) ^                       \
+                                         (((_w >> 8) & 0xffu) << _hs) ^ ((_w >> 16) & 0xffu)) & _hm; \
+                    _s = _h == _hp && MEMB(_x);                                               \
+                }                                                                             \
+                LV(_same) = _s;                                                               \
+            }                                                                                 \
+            if (GBALLOT(_same) != 0)                                                          \
+                (blocked) = 1;                                                                \
+        }                                                                                     \
     } while (0)
 
 /* evaluate candidates 64*B .. 64*B+63 (entries E); sets fin when the search is over.
@@ -232,9 +262,9 @@ DEV void sg_phase_begin(const LzJob &job, SgLds *lds, int w)
         LANEVAR(int, _dead);                                                                  \
         LANEVAR(int, _pass);                                                                  \
         LANEVAR(int, _maybe);                                                                 \
-        FOR_LANES                                                                             \
+        FOR_GLANES                                                                             \
         {                                                                                     \
-            const uint32_t _v = (B)*64u + (uint32_t)LANE;                                     \
+            const uint32_t _v = (B)*GRP + (uint32_t)GLANE;                                     \
             const uint32_t q = tileA + (LV(E) & ZD_TILE_MASK) - (_v < nA ? 0u : ZD_TILE);     \
             LV(_q) = q;                                                                       \
             LV(_alive) = _v == 0 || (_v < total && q > floor_pos); /* :1519 */                \
@@ -244,15 +274,15 @@ DEV void sg_phase_begin(const LzJob &job, SgLds *lds, int w)
             /* with another mem_level the candidate at exactly MAX_DIST can be the head of the \
              * reference's chain without being the first one here (LZ_HEAD_BLOCKED) */        \
             LANEVAR(int, _edge);                                                              \
-            FOR_LANES                                                                         \
+            FOR_GLANES                                                                         \
             {                                                                                 \
                 LV(_edge) = LV(_dead) && LV(_q) > st.base && p - LV(_q) == job.cfg.max_dist;  \
             }                                                                                 \
-            if (BALLOT(_edge) != 0) {                                                         \
+            if (GBALLOT(_edge) != 0) {                                                         \
                 int _blk;                                                                     \
-                LZ_HEAD_BLOCKED(p - job.cfg.max_dist, p, LZ_MEMB_ALL, _blk);                  \
+                SG_HEAD_BLOCKED(p - job.cfg.max_dist, p, LZ_MEMB_ALL, _blk);                  \
                 if (!_blk) {                                                                  \
-                    FOR_LANES                                                                 \
+                    FOR_GLANES                                                                 \
                     {                                                                         \
                         if (LV(_edge)) {                                                      \
                             LV(_alive) = 1;                                                   \
@@ -262,9 +292,9 @@ DEV void sg_phase_begin(const LzJob &job, SgLds *lds, int w)
                 }                                                                             \
             }                                                                                 \
         }                                                                                     \
-        const uint64_t _m_dead = BALLOT(_dead);                                               \
+        const uint64_t _m_dead = GBALLOT(_dead);                                               \
         SG_COUNT(0, 1);                                                                       \
-        FOR_LANES                                                                             \
+        FOR_GLANES                                                                             \
         {                                                                                     \
             /* lanes without a live candidate read the start of the ring and are masked */    \
             const int live = LV(_alive);                                                      \
@@ -276,14 +306,14 @@ DEV void sg_phase_begin(const LzJob &job, SgLds *lds, int w)
             LV(_pass) = live && g1 == sb && (w0 & 0xffffu) == (s0123 & 0xffffu);              \
             LV(_maybe) = live && w0 == s0123;                                                 \
         }                                                                                     \
-        uint64_t _todo = BALLOT(_pass);                                                       \
-        const uint64_t _m_maybe = cap > 3u ? BALLOT(_maybe) : 0ull;                           \
+        uint64_t _todo = GBALLOT(_pass);                                                       \
+        const uint64_t _m_maybe = cap > 3u ? GBALLOT(_maybe) : 0ull;                           \
         while (_todo != 0) {                                                                  \
             SG_COUNT(6, 1);                                                                   \
             /* passers that can beat best_len: any at all while best_len is 2, later only     \
              * those whose first four bytes match */                                          \
             const uint64_t _cand = best >= 3u ? (_todo & _m_maybe) : _todo;                   \
-            const int _j = _cand ? CTZ64(_cand) : 64;                                         \
+            const int _j = _cand ? CTZ64(_cand) : 64; /* (64: none; a group has fewer lanes) */                                         \
             const uint64_t _below = _j < 64 ? (_todo & ((1ull << _j) - 1ull)) : _todo;        \
             const uint32_t _nb = (uint32_t)POPC64(_below);                                    \
             if (_nb >= budget) {                                                              \
@@ -293,7 +323,7 @@ DEV void sg_phase_begin(const LzJob &job, SgLds *lds, int w)
             budget -= _nb;                                                                    \
             if (_j == 64)                                                                     \
                 break;                                                                        \
-            const uint32_t _qj = READLANE(_q, _j);                                            \
+            const uint32_t _qj = GREADLANE(_q, _j);                                            \
             uint32_t _len = 3;                                                                \
             if ((_m_maybe >> _j) & 1ull)                                                      \
                 SG_LCP(_qj, _len);                                                            \
@@ -314,14 +344,14 @@ DEV void sg_phase_begin(const LzJob &job, SgLds *lds, int w)
             if (_improved) {                                                                  \
                 SG_PEEK32(p + best - 1, sb);                                                  \
                 sb &= 0xffffu;                                                                \
-                FOR_LANES                                                                     \
+                FOR_GLANES                                                                     \
                 {                                                                             \
-                    const int live = LV(_alive) && LANE > _j &&                               \
+                    const int live = LV(_alive) && GLANE > _j &&                               \
                                      (LV(_w0) & 0xffffu) == (s0123 & 0xffffu);                \
                     const uint32_t r1 = live ? lz_ridx<L>(st, LV(_q) + best - 1) : 0u;        \
                     LV(_pass) = live && (lds_u32(lds->ring, r1) & 0xffffu) == sb;            \
                 }                                                                             \
-                _todo = BALLOT(_pass);                                                        \
+                _todo = GBALLOT(_pass);                                                        \
             } else {                                                                          \
                 _todo &= ~((2ull << _j) - 1ull);                                              \
             }                                                                                 \
@@ -354,21 +384,21 @@ DEV void sg_phase_begin(const LzJob &job, SgLds *lds, int w)
         uint32_t _qlo = floor_pos + 1u;         /* oldest live position (:1519) */            \
         if (job.cfg.hbits != 15u && floor_pos > st.base && p - floor_pos == job.cfg.max_dist) { \
             int _blk; /* the position at exactly MAX_DIST counts if it heads the reference's chain */ \
-            LZ_HEAD_BLOCKED(floor_pos, p, LZ_MEMB_ALL, _blk);                                 \
+            SG_HEAD_BLOCKED(floor_pos, p, LZ_MEMB_ALL, _blk);                                 \
             if (!_blk)                                                                        \
                 _qlo = floor_pos;                                                             \
         }                                                                                     \
         while (!fin && _qn >= _qlo) {                                                         \
             const uint32_t _off = best - 1u;                                                  \
             const uint32_t _rtop = _qn + _off, _rlo = _qlo + _off;                            \
-            const uint32_t _R0 = _rtop & ~1023u;                                              \
+            const uint32_t _R0 = _rtop & ~(16u * GRP - 1u);                                              \
             const uint32_t _sb2 = sb * 0x10001u;                                              \
             LANEVAR(uint32_t, _m16);                                                          \
             LANEVAR(int, _has);                                                               \
             SG_COUNT(0, 1);                                                                   \
-            FOR_LANES                                                                         \
+            FOR_GLANES                                                                         \
             {                                                                                 \
-                const uint32_t _x = _R0 + 16u * (uint32_t)LANE;                               \
+                const uint32_t _x = _R0 + 16u * (uint32_t)GLANE;                               \
                 uint32_t _m = 0;                                                              \
                 if (_x <= _rtop && _x + 16u > _rlo) {                                         \
                     const uint8_t *_src = &lds->ring[lz_ridx<L>(st, _x)];                     \
@@ -386,16 +416,16 @@ DEV void sg_phase_begin(const LzJob &job, SgLds *lds, int w)
                 LV(_m16) = _m;                                                                \
                 LV(_has) = _m != 0;                                                           \
             }                                                                                 \
-            uint64_t _any = BALLOT(_has);                                                     \
+            uint64_t _any = GBALLOT(_has);                                                     \
             int _moved = 0;                                                                   \
             while (_any != 0 && !_moved) {                                                    \
                 const int _l = 63 - CLZ64(_any);                                              \
-                uint32_t _mm = READLANE(_m16, _l);                                            \
+                uint32_t _mm = GREADLANE(_m16, _l);                                            \
                 while (_mm != 0) {                                                            \
                     const int _j = 31 - CLZ32(_mm);                                           \
                     _mm &= ~(1u << _j);                                                       \
                     const uint32_t _qj = _R0 + 16u * (uint32_t)_l + (uint32_t)_j - _off;      \
-                    const uint32_t _t = UNI(lds_u32(lds->ring, lz_ridx<L>(st, _qj)));         \
+                    const uint32_t _t = GUNI(lds_u32(lds->ring, lz_ridx<L>(st, _qj)));         \
                     if (((_t ^ s0123) & 0xffffffu) != 0)                                      \
                         continue; /* not on p's chain, or fails :1466-1467 */                 \
                     uint32_t _len = 3;                                                        \
@@ -442,15 +472,15 @@ DEV void sg_parse_segment(const LzJob &job, SgLds *lds, const SgScratch &scr, ui
 {
     typedef SgLds L;
     LzState st;
-    st.lo = UNI(lds->lo);
-    st.hi = UNI(lds->hi);
-    st.wrap_base = UNI(lds->wrap_base);
+    st.lo = GUNI(lds->lo);
+    st.hi = GUNI(lds->hi);
+    st.wrap_base = GUNI(lds->wrap_base);
     st.nsyms = st.nstaged = st.nblocks = st.blk_sym0 = st.blk_in0 = st.pr_hi = 0;
     st.n = job.n;
     st.si = 0;
     st.it = 0;
 
-    const uint32_t S0 = UNI(lds->S0);
+    const uint32_t S0 = GUNI(lds->S0);
     const uint64_t E64 = (uint64_t)S0 + SG_SPAN;
     const uint32_t E = E64 < job.n ? (uint32_t)E64 : job.n; /* end of the super-step */
     const uint32_t a_s = S0 + s * SG_G;
@@ -476,12 +506,12 @@ DEV void sg_parse_segment(const LzJob &job, SgLds *lds, const SgScratch &scr, ui
     LANEVAR(uint32_t, pv);
     LANEVAR(uint32_t, stg);
     LANEVAR(uint32_t, sdx);
-    FOR_LANES { LV(mrk) = LV(mcn) = LV(pv) = LV(stg) = LV(sdx) = 0; }
+    FOR_GLANES { LV(mrk) = LV(mcn) = LV(pv) = LV(stg) = LV(sdx) = 0; }
     /* the two caches start out of range of p, so that their one range test fails */
     uint32_t mt_at = p + 4096u, pv_at = 0xffffffffu;
     uint32_t lit = 0;                      /* the byte at p-1 */
     if (pending)
-        lit = UNI(lds->ring[lz_ridx<L>(st, p - 1u)]);
+        lit = GUNI(lds->ring[lz_ridx<L>(st, p - 1u)]);
     uint32_t tw = 0, tw_idx = 0xffffffffu; /* trace word being filled */
     uint32_t sd_blk = 0xffffffffu;         /* 64-position block sdx belongs to */
 
@@ -505,7 +535,7 @@ DEV void sg_parse_segment(const LzJob &job, SgLds *lds, const SgScratch &scr, ui
             if (fresh) {
                 /* the segment p lies in recorded the positions its own parser was fresh at */
                 const uint32_t t = (p - S0) / SG_G, r = (p - S0) % SG_G;
-                if ((UNI(lds->trace[t][r >> 5]) >> (r & 31u)) & 1u) {
+                if ((GUNI(lds->trace[t][r >> 5]) >> (r & 31u)) & 1u) {
                     exit_kind = SG_EXIT_SYNCED;
                     break;
                 }
@@ -518,21 +548,21 @@ DEV void sg_parse_segment(const LzJob &job, SgLds *lds, const SgScratch &scr, ui
             const uint32_t r = p - a_s;
             if ((r >> 5) != tw_idx) {
                 if (tw_idx != 0xffffffffu) {
-                    ON_LANE0 { lds->trace[s][tw_idx] = tw; }
+                    ON_GLANE0 { lds->trace[s][tw_idx] = tw; }
                 }
                 tw_idx = r >> 5;
                 tw = 0;
             }
             tw |= 1u << (r & 31u);
-            if ((r >> 6) != sd_blk) {
+            if (r / GRP != sd_blk) {
                 if (sd_blk != 0xffffffffu) {
-                    FOR_LANES { sidx[sd_blk * 64u + (uint32_t)LANE] = (uint16_t)LV(sdx); }
+                    FOR_GLANES { sidx[sd_blk * GRP + (uint32_t)GLANE] = (uint16_t)LV(sdx); }
                 }
-                sd_blk = r >> 6;
+                sd_blk = r / GRP;
             }
-            FOR_LANES
+            FOR_GLANES
             {
-                if ((uint32_t)LANE == (r & 63u))
+                if ((uint32_t)GLANE == r % GRP)
                     LV(sdx) = ntok;
             }
         }
@@ -542,17 +572,17 @@ DEV void sg_parse_segment(const LzJob &job, SgLds *lds, const SgScratch &scr, ui
         const uint32_t prev_len = cur_len, prev_at = cur_at;
         cur_len = 2;
         if (look >= 3 && prev_len < job.cfg.lazy) {
-            if (p - mt_at >= WAVE) {
+            if (p - mt_at >= GRP) {
                 mt_at = p;
-                FOR_LANES
+                FOR_GLANES
                 {
-                    const uint32_t x = p + (uint32_t)LANE;
+                    const uint32_t x = p + (uint32_t)GLANE;
                     const int ok = x + 2 < job.n;
                     LV(mrk) = ok ? ((uint32_t)job.rank[x] | ((uint32_t)job.hib[x] << 16)) : 0u;
                     LV(mcn) = ok ? job.cnt[x] : 0u;
                 }
             }
-            const uint32_t rh = READLANE(mrk, p - mt_at), cn = READLANE(mcn, p - mt_at);
+            const uint32_t rh = GREADLANE(mrk, p - mt_at), cn = GREADLANE(mcn, p - mt_at);
             const uint32_t nA = cn & 0xffffu, total = nA + (cn >> 16);
             if (total != 0) {
                 SG_COUNT(5, 1);
@@ -574,18 +604,18 @@ DEV void sg_parse_segment(const LzJob &job, SgLds *lds, const SgScratch &scr, ui
                 LANEVAR(uint32_t, f2);
                 LANEVAR(uint32_t, f3);
                 SG_LOAD(e0, 0u);
-                if (total > 64u) { /* most chains of text fit one load */
+                if (total > GRP) { /* most chains of text fit one load */
                     SG_LOAD(e1, 1u);
                     SG_LOAD(e2, 2u);
                     SG_LOAD(e3, 3u);
                 }
                 /* the chain head may lie at exactly MAX_DIST (:2032), later links may not */
-                const uint32_t ent0 = READLANE(e0, 0);
+                const uint32_t ent0 = GREADLANE(e0, 0);
                 const uint32_t q0 = tileA + (ent0 & ZD_TILE_MASK) - (nA ? 0u : ZD_TILE);
                 int head_ok = q0 > st.base && p - q0 <= job.cfg.max_dist;
                 if (head_ok && p - q0 == job.cfg.max_dist && job.cfg.hbits != 15u) {
                     int blocked;
-                    LZ_HEAD_BLOCKED(q0, p, LZ_MEMB_ALL, blocked);
+                    SG_HEAD_BLOCKED(q0, p, LZ_MEMB_ALL, blocked);
                     head_ok = !blocked;
                 }
                 if (!head_ok) {
@@ -604,16 +634,17 @@ DEV void sg_parse_segment(const LzJob &job, SgLds *lds, const SgScratch &scr, ui
                     }
                 }
                 int sweep = 0;
-                if (total > 256u) {
+                if (total > 4u * GRP) {
+                    /* a sweep step covers 16 GRP window positions, a walk step GRP candidates */
                     if (q0 > floor_pos)
-                        sweep = total > 128u * ((q0 - floor_pos) / 1024u + 2u);
+                        sweep = total > 2u * GRP * ((q0 - floor_pos) / (16u * GRP) + 2u);
                 }
                 if (fin) {
                 } else if (sweep) {
                     SG_SWEEP(q0);
                 } else {
                     for (uint32_t b0 = 0;; b0 += 4u) {
-                        const int more = (b0 + 4u) * 64u < total;
+                        const int more = (b0 + 4u) * GRP < total;
                         if (more) {
                             /* the next 256 candidates are on their way while these are looked at */
                             SG_LOAD(f0, b0 + 4u);
@@ -622,15 +653,15 @@ DEV void sg_parse_segment(const LzJob &job, SgLds *lds, const SgScratch &scr, ui
                             SG_LOAD(f3, b0 + 7u);
                         }
                         SG_EVAL(e0, b0);
-                        if (!fin && (b0 + 1u) * 64u < total)
+                        if (!fin && (b0 + 1u) * GRP < total)
                             SG_EVAL(e1, b0 + 1u);
-                        if (!fin && (b0 + 2u) * 64u < total)
+                        if (!fin && (b0 + 2u) * GRP < total)
                             SG_EVAL(e2, b0 + 2u);
-                        if (!fin && (b0 + 3u) * 64u < total)
+                        if (!fin && (b0 + 3u) * GRP < total)
                             SG_EVAL(e3, b0 + 3u);
                         if (fin || !more)
                             break;
-                        FOR_LANES
+                        FOR_GLANES
                         {
                             LV(e0) = LV(f0);
                             LV(e1) = LV(f1);
@@ -671,28 +702,28 @@ DEV void sg_parse_segment(const LzJob &job, SgLds *lds, const SgScratch &scr, ui
         }
         lit = s0123 & 0xffu; /* the byte a literal emitted by the next iteration stands for */
         if (emit) {
-            FOR_LANES
+            FOR_GLANES
             {
-                if ((uint32_t)LANE == nstaged)
+                if ((uint32_t)GLANE == nstaged)
                     LV(stg) = sym;
             }
             nstaged++;
             ntok++;
-            if (nstaged == WAVE) {
-                FOR_LANES { tok[ntok - WAVE + (uint32_t)LANE] = LV(stg); }
+            if (nstaged == GRP) {
+                FOR_GLANES { tok[ntok - GRP + (uint32_t)GLANE] = LV(stg); }
                 nstaged = 0;
             }
         }
     }
-    FOR_LANES
+    FOR_GLANES
     {
-        if ((uint32_t)LANE < nstaged)
-            tok[ntok - nstaged + (uint32_t)LANE] = LV(stg);
+        if ((uint32_t)GLANE < nstaged)
+            tok[ntok - nstaged + (uint32_t)GLANE] = LV(stg);
     }
     if (sd_blk != 0xffffffffu) {
-        FOR_LANES { sidx[sd_blk * 64u + (uint32_t)LANE] = (uint16_t)LV(sdx); }
+        FOR_GLANES { sidx[sd_blk * GRP + (uint32_t)GLANE] = (uint16_t)LV(sdx); }
     }
-    ON_LANE0
+    ON_GLANE0
     {
         if (tw_idx != 0xffffffffu)
             lds->trace[s][tw_idx] = tw;
@@ -714,40 +745,40 @@ DEV void sg_parse_segment(const LzJob &job, SgLds *lds, const SgScratch &scr, ui
  * that gave up) wave 0 parses on from that parser's exact state. */
 DEV void sg_phase_parse(const LzJob &job, SgLds *lds, const SgScratch &scr, int w)
 {
-    const uint32_t S0 = UNI(lds->S0);
+    const uint32_t S0 = GUNI(lds->S0);
     const uint32_t nact = sg_nact(S0, job.n);
-    const int redo = (int)UNI(lds->redo);
-    if (redo && w != 0)
+    const int redo = (int)GUNI(lds->redo);
+    if (redo && (w != 0 || GGROUP != 0)) /* one parser carries an exact state on */
         return;
     for (int round = 0;; round++) {
         uint32_t s, sp, slen = 2, sat = 0, spend = 0;
         if (redo) {
             if (round)
                 break;
-            const uint32_t k = UNI(lds->redo_from);
-            s = UNI(lds->redo_seg);
-            sp = UNI(lds->wv[k].exit_p);
-            slen = UNI(lds->wv[k].exit_len);
-            sat = UNI(lds->wv[k].exit_at);
-            spend = UNI(lds->wv[k].exit_pending);
+            const uint32_t k = GUNI(lds->redo_from);
+            s = GUNI(lds->redo_seg);
+            sp = GUNI(lds->wv[k].exit_p);
+            slen = GUNI(lds->wv[k].exit_len);
+            sat = GUNI(lds->wv[k].exit_at);
+            spend = GUNI(lds->wv[k].exit_pending);
         } else {
             LANEVAR(uint32_t, got);
-            FOR_LANES
+            FOR_GLANES
             {
                 LV(got) = 0;
-                if (LANE == 0)
+                if (GLANE == 0)
                     LV(got) = LDS_FETCH_ADD_U32(&lds->queue, 0xffffffffu);
             }
-            const uint32_t old = READLANE(got, 0);
+            const uint32_t old = GREADLANE(got, 0);
             if (old == 0 || old > nact) /* empty (the counter may have gone below zero) */
                 break;
-            s = UNI(lds->emu_ascending) ? nact - old : old - 1;
+            s = GUNI(lds->emu_ascending) ? nact - old : old - 1;
             sp = S0 + s * SG_G;
             if (s == 0) {
-                sp = UNI(lds->wv[0].start_p);
-                slen = UNI(lds->wv[0].start_len);
-                sat = UNI(lds->wv[0].start_at);
-                spend = UNI(lds->wv[0].start_pending);
+                sp = GUNI(lds->wv[0].start_p);
+                slen = GUNI(lds->wv[0].start_len);
+                sat = GUNI(lds->wv[0].start_at);
+                spend = GUNI(lds->wv[0].start_pending);
             }
         }
         SG_COUNT(2, redo ? 0x10000 + s : s);

@@ -26,7 +26,9 @@
 
 #include <stdint.h>
 
-#define WAVE 64
+#ifndef WAVE
+#define WAVE 64 /* (the host emulation is also built with 16, to run group code at its real width) */
+#endif
 
 #ifdef ZSC_WAVE_EMU
 /* ------------------------------------------------------------------ host */
@@ -216,6 +218,9 @@ DEV uint32_t lds_u32(const uint8_t *base, uint32_t idx)
 #define UNI(x) ((uint32_t)__builtin_amdgcn_readfirstlane((int)(x)))
 /* both sides 16-byte aligned: one global_load_dwordx4 + one ds_write_b128 */
 #define COPY16(dst, src) (*(uint4 *)(dst) = *(const uint4 *)(src))
+
 #endif
+
+#include "wave_group.h"
 
 #endif /* ZSC_WAVE_H */

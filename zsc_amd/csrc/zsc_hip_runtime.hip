@@ -255,7 +255,7 @@ __global__ __launch_bounds__(64) void k_parse(const uint8_t *__restrict__ in,
 /* kernel 2 for long buffers at levels 4-9: SG_W wavefronts share one window and parse
  * SG_W segments of the same buffer at once (lz_parse_seg.h) */
 template <bool GENERIC> /* false: window_bits 15 / mem_level 8, their constants folded in */
-__global__ __launch_bounds__(SG_W * 64, 6) void k_parse_seg(const uint8_t *__restrict__ in,
+__global__ __launch_bounds__(SG_W * 64, SG_MIN_WAVES) void k_parse_seg(const uint8_t *__restrict__ in,
                                                          const ZdBuf *__restrict__ bufs,
                                                          const uint32_t *__restrict__ order,
                                                          const uint32_t *__restrict__ sorted,
