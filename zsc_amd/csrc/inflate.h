@@ -86,12 +86,34 @@ typedef struct {
 #define INF_DATA (-3)
 #define INF_BUF (-5)
 
+/* The decoder is written for a group of lanes (wave_group.h): INF_GROUP lanes per stream,
+ * 64 / INF_GROUP streams per wavefront.  A stream is decoded by serial control flow; with a
+ * whole wave per stream that control flow is scalar instructions for one stream (47 of them
+ * per output byte, against 13 vector ones: profiles/), with four streams per wave the same
+ * instructions, now vector ones, serve four.  The groups stay close together in the symbol
+ * loop, which is where the time goes. */
+#ifndef INF_GROUP
+#define INF_GROUP 16
+#endif
+#undef ZSC_GROUP
+#define ZSC_GROUP INF_GROUP
+#include "wave_group.h"
+#if !defined(ZSC_WAVE_EMU) && INF_GROUP != 64
+#define CK_FN(name) ckg_##name
+#include "checksum_impl.h"
+#undef CK_FN
+#define INF_CK(name) ckg_##name
+#else
+#define INF_CK(name) ck_##name
+#endif
+#define INF_CHUNK (4u * GRP) /* input bytes held across the lanes of the group */
+
 /* build a canonical decoder from code lengths.  kind 0: code-length code, 1: literal/
  * length, 2: distance.  Returns 0, or -1 for an invalid set (src/inftrees.c:168-177). */
 DEV int inf_build(InfCode *c, const uint16_t *lens, int n, int kind)
 {
     int rc = 0;
-    ON_LANE0
+    ON_GLANE0
     {
         for (int i = 0; i < 16; i++)
             c->count[i] = 0;
@@ -148,9 +170,9 @@ DEV uint32_t inf_sync_search(const uint8_t *src, uint32_t n, uint64_t sy_start, 
     for (uint32_t k = 0; k < sy_rb; k += 8u) {
         const uint64_t bit = sy_start + k;
         const uint32_t by = (uint32_t)(bit >> 3), sh = (uint32_t)(bit & 7u);
-        uint32_t two = UNI(src[by]);
+        uint32_t two = GUNI(src[by]);
         if (sh && by + 1u < n)
-            two |= UNI(src[by + 1u]) << 8;
+            two |= GUNI(src[by + 1u]) << 8;
         hold |= ((two >> sh) & 0xffu) << k;
     }
     if (sy_rb < 32u)
@@ -160,11 +182,11 @@ DEV uint32_t inf_sync_search(const uint8_t *src, uint32_t n, uint64_t sy_start, 
     rb -= rb & 7u;
     const uint32_t nh = rb >> 3; /* bytes of hold searched before the input */
     const uint32_t vlen = nh + (n - nin);
-    for (uint32_t base = 0; base + 4u <= vlen; base += WAVE) {
+    for (uint32_t base = 0; base + 4u <= vlen; base += GRP) {
         LANEVAR(int, _hit);
-        FOR_LANES
+        FOR_GLANES
         {
-            const uint32_t m = base + (uint32_t)LANE;
+            const uint32_t m = base + (uint32_t)GLANE;
             int ok = m + 4u <= vlen;
             for (uint32_t j = 0; j < 4u && ok; j++) {
                 const uint32_t i = m + j;
@@ -173,7 +195,7 @@ DEV uint32_t inf_sync_search(const uint8_t *src, uint32_t n, uint64_t sy_start, 
             }
             LV(_hit) = ok;
         }
-        const uint64_t hm = BALLOT(_hit);
+        const uint64_t hm = GBALLOT(_hit);
         if (hm != 0) {
             const uint32_t found = base + (uint32_t)CTZ64(hm);
             return found + 4u > nh ? found + 4u - nh : 0u;
@@ -213,10 +235,10 @@ DEV int inflate_stream(const InfJob &job, InfLds *lds, InfResult *res, InfResume
     br.next = 0;
     br.chunk_at = 0;
     br.used = 0;
-    LANEVAR(uint32_t, cur); /* dword LANE of the current 256-byte input chunk */
-    FOR_LANES
+    LANEVAR(uint32_t, cur); /* dword GLANE of the current 256-byte input chunk */
+    FOR_GLANES
     {
-        uint32_t a = 4u * (uint32_t)LANE;
+        uint32_t a = 4u * (uint32_t)GLANE;
         uint32_t v = 0;
         if (a + 4 <= n)
             v = ld_u32(src + a);
@@ -227,7 +249,7 @@ DEV int inflate_stream(const InfJob &job, InfLds *lds, InfResult *res, InfResume
         LV(cur) = v;
     }
 
-    const int resumed = UNI(rs->state) == 1u;
+    const int resumed = GUNI(rs->state) == 1u;
     uint32_t pos = 0, flushed = 0; /* output bytes produced / stored to dst */
     uint32_t dmax = 32768u;
     int gzip = 0;
@@ -243,11 +265,11 @@ DEV int inflate_stream(const InfJob &job, InfLds *lds, InfResult *res, InfResume
 #define INF_REFILL()                                                                          \
     do {                                                                                      \
         while (br.bits <= 32 && br.next < n) {                                                \
-            if (br.next - br.chunk_at >= 256u) {                                              \
-                br.chunk_at += 256u;                                                          \
-                FOR_LANES                                                                     \
+            if (br.next - br.chunk_at >= INF_CHUNK) {                                              \
+                br.chunk_at += INF_CHUNK;                                                          \
+                FOR_GLANES                                                                     \
                 {                                                                             \
-                    uint32_t _a = br.chunk_at + 4u * (uint32_t)LANE;                          \
+                    uint32_t _a = br.chunk_at + 4u * (uint32_t)GLANE;                          \
                     uint32_t _v = 0;                                                          \
                     if (_a + 4 <= n)                                                          \
                         _v = ld_u32(src + _a);                                                \
@@ -259,7 +281,7 @@ DEV int inflate_stream(const InfJob &job, InfLds *lds, InfResult *res, InfResume
                 }                                                                             \
             }                                                                                 \
             const uint32_t _o = br.next - br.chunk_at;                                        \
-            const uint32_t _w = READLANE(cur, _o >> 2);                                       \
+            const uint32_t _w = GREADLANE(cur, _o >> 2);                                       \
             /* take the bytes of this dword from the current one on (up to 4) */              \
             uint32_t _take = 4u - (_o & 3u);                                                  \
             if (_take > n - br.next)                                                          \
@@ -320,11 +342,11 @@ DEV int inflate_stream(const InfJob &job, InfLds *lds, InfResult *res, InfResume
         br.hold = 0;                                                                          \
         br.bits = 0;                                                                          \
         br.next = (P);                                                                        \
-        if (br.next - br.chunk_at >= 256u || br.next < br.chunk_at) {                         \
-            br.chunk_at = br.next & ~255u;                                                    \
-            FOR_LANES                                                                         \
+        if (br.next - br.chunk_at >= INF_CHUNK || br.next < br.chunk_at) {                         \
+            br.chunk_at = br.next & ~(INF_CHUNK - 1u);                                                    \
+            FOR_GLANES                                                                         \
             {                                                                                 \
-                uint32_t _a = br.chunk_at + 4u * (uint32_t)LANE;                              \
+                uint32_t _a = br.chunk_at + 4u * (uint32_t)GLANE;                              \
                 uint32_t _w = 0;                                                              \
                 if (_a + 4 <= n)                                                              \
                     _w = ld_u32(src + _a);                                                    \
@@ -343,9 +365,16 @@ DEV int inflate_stream(const InfJob &job, InfLds *lds, InfResult *res, InfResume
         uint32_t _upto = (all) ? pos : (pos & ~255u);                                          \
         while (flushed < _upto) {                                                              \
             uint32_t _len = _upto - flushed < 256u ? _upto - flushed : 256u;                   \
-            FOR_LANES                                                                          \
+            FOR_GLANES                                                                         \
             {                                                                                  \
-                for (uint32_t _k = (uint32_t)LANE; _k < _len; _k += WAVE)                      \
+                /* (flushed is a multiple of 256 and dst 16-byte aligned: whole dwords, then the \
+                 * last bytes of the stream) */                                                \
+                for (uint32_t _k = 4u * (uint32_t)GLANE; _k + 4u <= _len; _k += 4u * GRP) {    \
+                    uint32_t _w;                                                               \
+                    __builtin_memcpy(&_w, &lds->stage[(flushed + _k) & (INF_STAGE - 1)], 4);   \
+                    __builtin_memcpy(dst + flushed + _k, &_w, 4);                              \
+                }                                                                              \
+                for (uint32_t _k = (_len & ~3u) + (uint32_t)GLANE; _k < _len; _k += GRP)       \
                     dst[flushed + _k] = lds->stage[(flushed + _k) & (INF_STAGE - 1)];          \
             }                                                                                  \
             flushed += _len;                                                                   \
@@ -369,9 +398,9 @@ DEV int inflate_stream(const InfJob &job, InfLds *lds, InfResult *res, InfResume
         const uint32_t _peek = (uint32_t)br.hold & 0x7fffu;                                   \
         const uint32_t _r = BREV32(_peek) >> 17; /* the 15 bits MSB first */                  \
         LANEVAR(int, _hit);                                                                   \
-        FOR_LANES                                                                             \
+        FOR_GLANES                                                                             \
         {                                                                                     \
-            int _l = LANE;                                                                    \
+            int _l = GLANE;                                                                    \
             int _ok = 0;                                                                      \
             if (_l >= 1 && _l <= (int)(C)->max_len) {                                         \
                 uint32_t _c = _r >> (15 - _l);                                                \
@@ -379,7 +408,7 @@ DEV int inflate_stream(const InfJob &job, InfLds *lds, InfResult *res, InfResume
             }                                                                                 \
             LV(_hit) = _ok;                                                                   \
         }                                                                                     \
-        const uint64_t _m = BALLOT(_hit);                                                     \
+        const uint64_t _m = GBALLOT(_hit);                                                     \
         if (_m == 0) {                                                                        \
             /* no code matches: only possible for the lone 1-bit code (incomplete set) */     \
             INF_NEED((C)->max_len);                                                           \
@@ -420,14 +449,14 @@ DEV int inflate_stream(const InfJob &job, InfLds *lds, InfResult *res, InfResume
         const uint32_t _peek = (uint32_t)br.hold & 0x7fffu;                                   \
         const uint32_t _r = BREV32(_peek) >> 17; /* the 15 bits MSB first */                  \
         LANEVAR(int, _hit);                                                                   \
-        FOR_LANES                                                                             \
+        FOR_GLANES                                                                             \
         {                                                                                     \
-            const uint32_t _l = (uint32_t)LANE;                                               \
+            const uint32_t _l = (uint32_t)GLANE;                                               \
             const uint32_t _c = _r >> ((15u - _l) & 31u);                                     \
             LV(_hit) = _l >= 1u && _l <= (MAXLEN) &&                                          \
                        (uint32_t)(_c - (LV(FC) & 0xffffu)) < (LV(FC) >> 16);                  \
         }                                                                                     \
-        const uint64_t _m = BALLOT(_hit);                                                     \
+        const uint64_t _m = GBALLOT(_hit);                                                     \
         if (_m == 0) {                                                                        \
             INF_NEED(MAXLEN);                                                                 \
             uint32_t _d;                                                                      \
@@ -443,7 +472,7 @@ DEV int inflate_stream(const InfJob &job, InfLds *lds, InfResult *res, InfResume
             goto done;                                                                        \
         }                                                                                     \
         const uint32_t _code = _r >> (15 - _len);                                             \
-        (OUTSYM) = (int)UNI((C)->sym[READLANE(OF, _len) + (_code - (READLANE(FC, _len) & 0xffffu))]); \
+        (OUTSYM) = (int)GUNI((C)->sym[GREADLANE(OF, _len) + (_code - (GREADLANE(FC, _len) & 0xffffu))]); \
         br.hold >>= _len;                                                                     \
         br.bits -= _len;                                                                      \
         br.used += _len;                                                                      \
@@ -459,11 +488,11 @@ DEV int inflate_stream(const InfJob &job, InfLds *lds, InfResult *res, InfResume
          * src/inflate.c:1547-1604): find the next 00 00 FF FF -- first in what was left of the
          * bit buffer, then in the input -- and decode on from there as a raw stream: mode =
          * TYPE, empty window, the totals and the check value carry on */
-        pos = flushed = out_base = UNI(rs->out_pos);
-        data_errors = UNI(rs->errors);
-        gzip = (int)UNI(rs->gzip);
-        const uint64_t sy0 = ((uint64_t)UNI(rs->sy_hi) << 32) | UNI(rs->sy_lo);
-        const uint32_t rb0 = UNI(rs->sy_rb);
+        pos = flushed = out_base = GUNI(rs->out_pos);
+        data_errors = GUNI(rs->errors);
+        gzip = (int)GUNI(rs->gzip);
+        const uint64_t sy0 = ((uint64_t)GUNI(rs->sy_hi) << 32) | GUNI(rs->sy_lo);
+        const uint32_t rb0 = GUNI(rs->sy_rb);
         const uint32_t nin = (uint32_t)((sy0 + rb0) >> 3); /* the reference's next_in */
         if (nin >= n && rb0 < 8u) {                         /* :1562-1565 */
             rc = INF_BUF;
@@ -518,7 +547,7 @@ DEV int inflate_stream(const InfJob &job, InfLds *lds, InfResult *res, InfResume
                 uint32_t got;
                 INF_NEED(16);
                 INF_TAKE(got, 16);
-                if ((wrap & 4) && got != (ck_crc32_t<1>(src, upto, &lds->ck) & 0xffffu))
+                if ((wrap & 4) && got != (INF_CK(crc32_t)<1>(src, upto, &lds->ck) & 0xffffu))
                     INF_BADX(16, 16); /* :944-950 */
             }
         } else {
@@ -577,9 +606,9 @@ DEV int inflate_stream(const InfJob &job, InfLds *lds, InfResult *res, InfResume
             /* copy through the staging area, 256 bytes per step */
             for (uint32_t k = 0; k < can; k += 256u) {
                 const uint32_t step = can - k < 256u ? can - k : 256u;
-                FOR_LANES
+                FOR_GLANES
                 {
-                    for (uint32_t j = (uint32_t)LANE; j < step; j += WAVE)
+                    for (uint32_t j = (uint32_t)GLANE; j < step; j += GRP)
                         lds->stage[(pos + j) & (INF_STAGE - 1)] = src[at + k + j];
                 }
                 WAVE_SYNC();
@@ -593,17 +622,17 @@ DEV int inflate_stream(const InfJob &job, InfLds *lds, InfResult *res, InfResume
             }
         } else {
             if (type == 1) {
-                FOR_LANES
+                FOR_GLANES
                 {
-                    for (int s = LANE; s < 288; s += WAVE)
+                    for (int s = GLANE; s < 288; s += GRP)
                         lds->lens[s] = (uint16_t)(s < 144 ? 8 : s < 256 ? 9 : s < 280 ? 7 : 8);
                 }
                 WAVE_SYNC();
                 (void)inf_build(&lds->lit, lds->lens, 288, 1);
-                FOR_LANES
+                FOR_GLANES
                 {
-                    if (LANE < 32)
-                        lds->lens[LANE] = 5;
+                    for (int s = GLANE; s < 32; s += GRP)
+                        lds->lens[s] = 5;
                 }
                 WAVE_SYNC();
                 (void)inf_build(&lds->dist, lds->lens, 32, 2);
@@ -618,10 +647,10 @@ DEV int inflate_stream(const InfJob &job, InfLds *lds, InfResult *res, InfResume
                 ncode += 4;
                 if (nlen > 286 || ndist > 30)
                     INF_BAD;
-                FOR_LANES
+                FOR_GLANES
                 {
-                    if (LANE < 19)
-                        lds->lens[LANE] = 0;
+                    for (int s = GLANE; s < 19; s += GRP)
+                        lds->lens[s] = 0;
                 }
                 WAVE_SYNC();
                 for (uint32_t i = 0; i < ncode; i++) {
@@ -629,7 +658,7 @@ DEV int inflate_stream(const InfJob &job, InfLds *lds, InfResult *res, InfResume
                     INF_NEED(3);
                     INF_TAKE(v, 3);
                     const uint8_t order[19] = {16, 17, 18, 0, 8, 7, 9, 6, 10, 5, 11, 4, 12, 3, 13, 2, 14, 1, 15};
-                    ON_LANE0 { lds->lens[order[i]] = (uint16_t)v; }
+                    ON_GLANE0 { lds->lens[order[i]] = (uint16_t)v; }
                     WAVE_SYNC();
                 }
                 if (inf_build(&lds->cl, lds->lens, 19, 0))
@@ -641,7 +670,7 @@ DEV int inflate_stream(const InfJob &job, InfLds *lds, InfResult *res, InfResume
                     if (sym < 0)
                         sym = 0; /* all-zero code-length code: CODELENS reads the marker's val 0, bits 1 (:1105-1114) */
                     if (sym < 16) {
-                        ON_LANE0 { lds->lens[have] = (uint16_t)sym; }
+                        ON_GLANE0 { lds->lens[have] = (uint16_t)sym; }
                         WAVE_SYNC();
                         have++;
                         continue;
@@ -668,9 +697,9 @@ DEV int inflate_stream(const InfJob &job, InfLds *lds, InfResult *res, InfResume
                     }
                     if (have + rep > nlen + ndist)
                         INF_BAD;
-                    FOR_LANES
+                    FOR_GLANES
                     {
-                        for (uint32_t k = (uint32_t)LANE; k < rep; k += WAVE)
+                        for (uint32_t k = (uint32_t)GLANE; k < rep; k += GRP)
                             lds->lens[have + k] = (uint16_t)val;
                     }
                     WAVE_SYNC();
@@ -689,16 +718,16 @@ DEV int inflate_stream(const InfJob &job, InfLds *lds, InfResult *res, InfResume
             LANEVAR(uint32_t, lof);
             LANEVAR(uint32_t, dfc);
             LANEVAR(uint32_t, dof);
-            FOR_LANES
+            FOR_GLANES
             {
-                const int l = LANE & 15;
+                const int l = GLANE & 15;
                 LV(lfc) = (uint32_t)lds->lit.first[l] | ((uint32_t)lds->lit.count[l] << 16);
                 LV(lof) = lds->lit.offs[l];
                 LV(dfc) = (uint32_t)lds->dist.first[l] | ((uint32_t)lds->dist.count[l] << 16);
                 LV(dof) = lds->dist.offs[l];
             }
-            const uint32_t lmax = UNI(lds->lit.max_len), lempty = UNI(lds->lit.empty);
-            const uint32_t dmaxlen = UNI(lds->dist.max_len), dempty = UNI(lds->dist.empty);
+            const uint32_t lmax = GUNI(lds->lit.max_len), lempty = GUNI(lds->lit.empty);
+            const uint32_t dmaxlen = GUNI(lds->dist.max_len), dempty = GUNI(lds->dist.empty);
             for (;;) {
                 int sym;
                 INF_DECODE_R(&lds->lit, lfc, lof, lmax, lempty, sym);
@@ -709,7 +738,7 @@ DEV int inflate_stream(const InfJob &job, InfLds *lds, InfResult *res, InfResume
                         rc = INF_BUF;
                         goto done;
                     }
-                    ON_LANE0 { lds->stage[pos & (INF_STAGE - 1)] = (uint8_t)sym; }
+                    ON_GLANE0 { lds->stage[pos & (INF_STAGE - 1)] = (uint8_t)sym; }
                     WAVE_SYNC();
                     pos++;
                     if ((pos & 255u) == 0)
@@ -745,10 +774,10 @@ DEV int inflate_stream(const InfJob &job, InfLds *lds, InfResult *res, InfResume
                 if (can > cap - pos)
                     can = cap - pos;
                 /* lane-parallel copy: byte i comes from pos - dist + (i mod dist) */
-                for (uint32_t k = 0; k < can; k += WAVE) {
-                    FOR_LANES
+                for (uint32_t k = 0; k < can; k += GRP) {
+                    FOR_GLANES
                     {
-                        uint32_t i = k + (uint32_t)LANE;
+                        uint32_t i = k + (uint32_t)GLANE;
                         if (i < can) {
                             uint32_t s = pos - dist + (i % dist);
                             uint8_t b = s >= flushed ? lds->stage[s & (INF_STAGE - 1)] : dst[s];
@@ -787,7 +816,7 @@ DEV int inflate_stream(const InfJob &job, InfLds *lds, InfResult *res, InfResume
 #ifndef ZSC_WAVE_EMU
                 __threadfence_block();
 #endif
-                const uint32_t want = gzip ? ck_crc32_t<1>(dst, pos, &lds->ck) : ck_adler32(dst, pos);
+                const uint32_t want = gzip ? INF_CK(crc32_t)<1>(dst, pos, &lds->ck) : INF_CK(adler32)(dst, pos);
                 const uint32_t got = gzip ? v : ((v >> 24) | ((v >> 8) & 0xff00u) | ((v & 0xff00u) << 8) | (v << 24));
                 if (got != want)
                     INF_BADX(32, 32); /* :1333-1339 */
@@ -807,7 +836,7 @@ bad:
     /* a data error: hand the state inflateSync starts from to the next entry */
     data_errors++;
     INF_FLUSH(1);
-    ON_LANE0
+    ON_GLANE0
     {
         rs->state = 1;
         rs->out_pos = pos;
@@ -822,7 +851,7 @@ bad:
 
 done:
     INF_FLUSH(1);
-    ON_LANE0
+    ON_GLANE0
     {
         uint32_t used_bytes = (uint32_t)((br.used + 7u) >> 3);
         if (exhausted || used_bytes > n)
@@ -858,5 +887,10 @@ DEV void inflate_with_resync(const InfJob &job, InfLds *lds, InfResult *res)
             return;
     }
 }
+
+/* back to whole-wave groups for whatever is compiled after this */
+#undef ZSC_GROUP
+#define ZSC_GROUP 64
+#include "wave_group.h"
 
 #endif

@@ -605,8 +605,9 @@ typedef struct {
     uint32_t src_len, dst_cap;
 } ZdInfItem;
 
-/* kernel 5: one wavefront per compressed stream */
-__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(7, 8))) void k_inflate(const uint8_t *__restrict__ src,
+/* kernel 5: one group of INF_GROUP lanes per compressed stream, 64 / INF_GROUP streams per wavefront */
+#define INF_PER_WAVE (64 / INF_GROUP)
+__global__ __launch_bounds__(64) void k_inflate(const uint8_t *__restrict__ src,
                                                 uint8_t *__restrict__ dst,
                                                 const ZdInfItem *__restrict__ items,
                                                 const uint32_t *__restrict__ order,
@@ -615,10 +616,13 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(7, 8))) void
                                                 uint32_t *__restrict__ pending, int32_t window_bits,
                                                 uint32_t count)
 {
-    __shared__ InfLds lds;
-    if (blockIdx.x >= count)
+    __shared__ InfLds lds_all[INF_PER_WAVE];
+    const uint32_t grp = (threadIdx.x & 63u) / INF_GROUP;
+    InfLds *lds = &lds_all[grp];
+    const uint32_t slot = blockIdx.x * INF_PER_WAVE + grp;
+    if (slot >= count)
         return;
-    const uint32_t i = order[blockIdx.x];
+    const uint32_t i = order[slot];
     if (resume[i].state == 2u)
         return; /* finished in an earlier launch (only streams that resynchronise come back) */
     const ZdInfItem it = items[i];
@@ -628,8 +632,8 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(7, 8))) void
     job.dst = dst + it.dst_off;
     job.cap = it.dst_cap;
     job.window_bits = window_bits;
-    if (inflate_stream(job, &lds, &res[i], &resume[i])) {
-        if ((threadIdx.x & 63) == 0)
+    if (inflate_stream(job, lds, &res[i], &resume[i])) {
+        if ((threadIdx.x & (INF_GROUP - 1u)) == 0)
             atomicAdd(pending, 1u); /* the host launches once more for these */
     }
 }
@@ -2320,7 +2324,7 @@ extern "C" ZlibReturn zsc_hip_inflate_plan_run(zsc_hip_inflate_plan *pl, const v
     HIP_TRY(hipMemsetAsync(pl->d_resume.p, 0, sizeof(InfResume) * pl->count, st), return Z_STREAM_ERROR);
     HIP_TRY(hipMemsetAsync(pl->d_pending.p, 0, 4, st), return Z_STREAM_ERROR);
     (void)hipEventRecord(pl->ev0, st);
-    hipLaunchKernelGGL(k_inflate, dim3(pl->count), dim3(64), 0, st, (const uint8_t *)d_src,
+    hipLaunchKernelGGL(k_inflate, dim3((pl->count + INF_PER_WAVE - 1) / INF_PER_WAVE), dim3(64), 0, st, (const uint8_t *)d_src,
                        (uint8_t *)d_dst, (const ZdInfItem *)pl->d_items.p,
                        (const uint32_t *)pl->d_order.p, (InfResult *)pl->d_res.p,
                        (InfResume *)pl->d_resume.p, (uint32_t *)pl->d_pending.p, pl->window_bits,
@@ -2346,7 +2350,7 @@ extern "C" ZlibReturn zsc_hip_inflate_plan_results(zsc_hip_inflate_plan *pl, U32
         if (pending == 0 || round > (1u << 30))
             break;
         HIP_TRY(hipMemsetAsync(pl->d_pending.p, 0, 4, pl->last_stream), return Z_STREAM_ERROR);
-        hipLaunchKernelGGL(k_inflate, dim3(pl->count), dim3(64), 0, pl->last_stream,
+        hipLaunchKernelGGL(k_inflate, dim3((pl->count + INF_PER_WAVE - 1) / INF_PER_WAVE), dim3(64), 0, pl->last_stream,
                            (const uint8_t *)pl->last_src, (uint8_t *)pl->last_dst,
                            (const ZdInfItem *)pl->d_items.p, (const uint32_t *)pl->d_order.p,
                            (InfResult *)pl->d_res.p, (InfResume *)pl->d_resume.p,
