@@ -458,6 +458,8 @@ extern "C" int emu_uncompress(const uint8_t *src, uint32_t n, int window_bits, u
     InfJob job = {in.data(), n, out.data(), cap, window_bits};
     InfLds *lds = (InfLds *)malloc(sizeof(InfLds));
     memset(lds, 0x3C, sizeof(InfLds));
+    static uint32_t crc_table[1][256];
+    lds->cktab = crc_table;
     InfResult res;
     inflate_with_resync(job, lds, &res);
     free(lds);

@@ -48,7 +48,7 @@ DEV uint32_t CK_FN(adler32)(const uint8_t *in, uint32_t n)
 }
 
 template <int NT>
-DEV uint32_t CK_FN(crc32_t)(const uint8_t *in, uint32_t n, CkLdsT<NT> *lds)
+DEV uint32_t CK_FN(crc32_tx)(const uint8_t *in, uint32_t n, uint32_t (*table)[256], uint32_t *xch)
 {
     for (int i = 0; i < 256; i += GRP) {
         FOR_GLANES
@@ -56,7 +56,7 @@ DEV uint32_t CK_FN(crc32_t)(const uint8_t *in, uint32_t n, CkLdsT<NT> *lds)
             uint32_t c = (uint32_t)(i + GLANE);
             for (int k = 0; k < 8; k++)
                 c = (c & 1u) ? 0xEDB88320u ^ (c >> 1) : c >> 1;
-            lds->table[0][i + GLANE] = c;
+            table[0][i + GLANE] = c;
         }
     }
     WAVE_SYNC();
@@ -64,8 +64,8 @@ DEV uint32_t CK_FN(crc32_t)(const uint8_t *in, uint32_t n, CkLdsT<NT> *lds)
         for (int i = 0; i < 256; i += GRP) {
             FOR_GLANES
             {
-                const uint32_t c = lds->table[t - 1][i + GLANE];
-                lds->table[t][i + GLANE] = lds->table[0][c & 0xffu] ^ (c >> 8);
+                const uint32_t c = table[t - 1][i + GLANE];
+                table[t][i + GLANE] = table[0][c & 0xffu] ^ (c >> 8);
             }
         }
         WAVE_SYNC();
@@ -92,42 +92,42 @@ DEV uint32_t CK_FN(crc32_t)(const uint8_t *in, uint32_t n, CkLdsT<NT> *lds)
                 for (int q = 0; q < 4; q++) {
                     r ^= w[q];
                     if (NT >= 4) {
-                        r = lds->table[3 % NT][r & 0xffu] ^ lds->table[2 % NT][(r >> 8) & 0xffu] ^
-                            lds->table[1 % NT][(r >> 16) & 0xffu] ^ lds->table[0][r >> 24];
+                        r = table[3 % NT][r & 0xffu] ^ table[2 % NT][(r >> 8) & 0xffu] ^
+                            table[1 % NT][(r >> 16) & 0xffu] ^ table[0][r >> 24];
                     } else {
                         for (int b = 0; b < 4; b++)
-                            r = lds->table[0][r & 0xffu] ^ (r >> 8);
+                            r = table[0][r & 0xffu] ^ (r >> 8);
                     }
                 }
             }
             for (; i < hi; i++)
-                r = lds->table[0][(r ^ in[i]) & 0xffu] ^ (r >> 8);
+                r = table[0][(r ^ in[i]) & 0xffu] ^ (r >> 8);
         }
         LV(c) = r;
     }
     /* the lanes before `last` hold full segments: bring them to the top of the wave, the last
      * full one to lane 63, zeros below */
     const uint32_t shift = (GRP - 1u) - (last ? last - 1u : 0u); /* lanes to move up (last >= 1) */
-    FOR_GLANES { lds->x[GLANE] = LV(c); }
+    FOR_GLANES { xch[GLANE] = LV(c); }
     WAVE_SYNC();
-    const uint32_t c_last = GUNI(lds->x[last]);
+    const uint32_t c_last = GUNI(xch[last]);
     LANEVAR(uint32_t, v);
     FOR_GLANES
     {
         const uint32_t l = (uint32_t)GLANE;
-        LV(v) = (last != 0u && l >= shift) ? lds->x[l - shift] : 0u;
+        LV(v) = (last != 0u && l >= shift) ? xch[l - shift] : 0u;
     }
     WAVE_SYNC();
     /* log-steps: the value at the right end of a block of 2d lanes becomes left * X^d + right */
     for (uint32_t m = 0; (1u << m) < GRP; m++) {
         const uint32_t d = 1u << m;
         const uint32_t xd = ck_x2n(3u + k + m); /* X^d = x^(8 S d) */
-        FOR_GLANES { lds->x[GLANE] = LV(v); }
+        FOR_GLANES { xch[GLANE] = LV(v); }
         WAVE_SYNC();
         FOR_GLANES
         {
             const uint32_t l = (uint32_t)GLANE;
-            const uint32_t left = l >= d ? lds->x[l - d] : 0u;
+            const uint32_t left = l >= d ? xch[l - d] : 0u;
             const uint32_t comb = ck_mulmod(left, xd) ^ LV(v);
             if ((l & (2u * d - 1u)) == 2u * d - 1u)
                 LV(v) = comb;
@@ -145,17 +145,25 @@ DEV uint32_t CK_FN(crc32_t)(const uint8_t *in, uint32_t n, CkLdsT<NT> *lds)
         LV(f) = prod;
     }
     for (uint32_t d = 1; d < GRP; d <<= 1) {
-        FOR_GLANES { lds->x[GLANE] = LV(f); }
+        FOR_GLANES { xch[GLANE] = LV(f); }
         WAVE_SYNC();
-        FOR_GLANES { LV(f) = ck_mulmod(LV(f), lds->x[(uint32_t)GLANE ^ d]); }
+        FOR_GLANES { LV(f) = ck_mulmod(LV(f), xch[(uint32_t)GLANE ^ d]); }
         WAVE_SYNC();
     }
     /* (every lane ends up with the whole product) */
-    FOR_GLANES { lds->x[GLANE] = GLANE == 0 ? LV(f) : LV(v); }
+    FOR_GLANES { xch[GLANE] = GLANE == 0 ? LV(f) : LV(v); }
     WAVE_SYNC();
-    const uint32_t pw = GUNI(lds->x[0]), vtop = GUNI(lds->x[GRP - 1u]);
+    const uint32_t pw = GUNI(xch[0]), vtop = GUNI(xch[GRP - 1u]);
     WAVE_SYNC();
     const uint32_t total = ck_mulmod(vtop, pw) ^ c_last;
     return ~total;
 }
 
+
+/* (the tables may be shared by the groups of a wave: every group writes all of them, with the
+ * same values, before it reads any; the exchange area is the group's own) */
+template <int NT>
+DEV uint32_t CK_FN(crc32_t)(const uint8_t *in, uint32_t n, CkLdsT<NT> *lds)
+{
+    return CK_FN(crc32_tx)<NT>(in, n, lds->table, lds->x);
+}

@@ -32,21 +32,26 @@
 
 #define INF_STAGE 1024u
 
-typedef struct {
+template <int NSYM>
+struct InfCodeT {
     uint16_t count[16];
     uint16_t first[16]; /* first canonical code of each length */
     uint16_t offs[16];  /* index of that code's symbol in sym[] */
     uint16_t fill[16];  /* scratch of inf_build */
-    uint16_t sym[320];
+    uint16_t sym[NSYM];
     uint32_t max_len;
     uint32_t empty;
-} InfCode;
+};
 
+/* per stream: 3.7 KiB, so that four streams per wave leave room for twelve waves on a CU */
 typedef struct {
-    InfCode lit, dist, cl;
+    InfCodeT<288> lit;
+    InfCodeT<32> dist;
+    InfCodeT<20> cl;
     uint16_t lens[320];
     uint8_t stage[INF_STAGE + 320]; /* output not yet stored: [flushed, pos) */
-    CkLdsT<1> ck; /* the byte-loop tables: the decoder wants its LDS for waves, not for tables */
+    uint32_t ckx[64];               /* exchange area of the CRC routine */
+    uint32_t (*cktab)[256];         /* its byte-loop table (1 KiB), shared by the streams of a wave */
 } InfLds;
 
 /* where decoding goes on after an inflateSync: the stream is inflated again from there */
@@ -110,7 +115,8 @@ typedef struct {
 
 /* build a canonical decoder from code lengths.  kind 0: code-length code, 1: literal/
  * length, 2: distance.  Returns 0, or -1 for an invalid set (src/inftrees.c:168-177). */
-DEV int inf_build(InfCode *c, const uint16_t *lens, int n, int kind)
+template <class CT>
+DEV int inf_build(CT *c, const uint16_t *lens, int n, int kind)
 {
     int rc = 0;
     ON_GLANE0
@@ -547,7 +553,7 @@ DEV int inflate_stream(const InfJob &job, InfLds *lds, InfResult *res, InfResume
                 uint32_t got;
                 INF_NEED(16);
                 INF_TAKE(got, 16);
-                if ((wrap & 4) && got != (INF_CK(crc32_t)<1>(src, upto, &lds->ck) & 0xffffu))
+                if ((wrap & 4) && got != (INF_CK(crc32_tx)<1>(src, upto, lds->cktab, lds->ckx) & 0xffffu))
                     INF_BADX(16, 16); /* :944-950 */
             }
         } else {
@@ -816,7 +822,7 @@ DEV int inflate_stream(const InfJob &job, InfLds *lds, InfResult *res, InfResume
 #ifndef ZSC_WAVE_EMU
                 __threadfence_block();
 #endif
-                const uint32_t want = gzip ? INF_CK(crc32_t)<1>(dst, pos, &lds->ck) : INF_CK(adler32)(dst, pos);
+                const uint32_t want = gzip ? INF_CK(crc32_tx)<1>(dst, pos, lds->cktab, lds->ckx) : INF_CK(adler32)(dst, pos);
                 const uint32_t got = gzip ? v : ((v >> 24) | ((v >> 8) & 0xff00u) | ((v & 0xff00u) << 8) | (v << 24));
                 if (got != want)
                     INF_BADX(32, 32); /* :1333-1339 */

@@ -617,8 +617,11 @@ __global__ __launch_bounds__(64) void k_inflate(const uint8_t *__restrict__ src,
                                                 uint32_t count)
 {
     __shared__ InfLds lds_all[INF_PER_WAVE];
+    __shared__ uint32_t crc_table[1][256];
     const uint32_t grp = (threadIdx.x & 63u) / INF_GROUP;
     InfLds *lds = &lds_all[grp];
+    if ((threadIdx.x & (INF_GROUP - 1u)) == 0)
+        lds->cktab = crc_table;
     const uint32_t slot = blockIdx.x * INF_PER_WAVE + grp;
     if (slot >= count)
         return;
