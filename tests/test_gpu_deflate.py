@@ -348,3 +348,40 @@ def test_short_soak():
     r = subprocess.run([sys.executable, os.path.join(root, "tools", "soak.py"), "15", "11"],
                        capture_output=True, text=True, timeout=600)
     assert r.returncode == 0 and " 0 mismatches" in r.stdout, (r.stdout[-600:], r.stderr[-600:])
+
+
+@pytest.mark.gpu
+def test_config_1_single_64k_buffer_one_shot(oracle):
+    """BASELINE config 1, literally: ONE 65 536-byte buffer through the one-shot zsc_compress at
+    level 6 (max_block_len >= source_len), compared with the oracle byte for byte, and back."""
+    import zsc_amd
+    for kind in ("text", "random", "zero", "table"):
+        data = corpus.make_buffer(kind, 65536, 2024)
+        rc, got = zsc_amd.compress(data, level=6, max_block_len=65536)
+        orc, want, _ = oracle.compress(data, 6)
+        assert rc == orc == 0 and got == want, kind
+        rc, back, used = zsc_amd.uncompress(got, 65536)
+        assert (rc, back, used) == (0, data, len(got)), kind
+
+
+@pytest.mark.gpu
+def test_buffer_too_long_for_32_bit_stream_positions_is_refused():
+    """Bit positions inside one stream are 32-bit: a buffer whose stream could pass 2^32 bits is
+    refused when the plan is made (Z_MEM_ERROR), not compressed into a corrupt stream."""
+    import zsc_amd
+    with pytest.raises(RuntimeError, match="-4"):
+        zsc_amd.DeflatePlan([0x1ff00000], level=6)
+    zsc_amd.DeflatePlan([1 << 20], level=6).close()
+
+
+@pytest.mark.gpu
+def test_gzip_trailer_crc_of_many_lengths(oracle):
+    """The CRC-32 kernel (checksum.h) through the gzip wrapper, at lengths around its segment
+    sizes (64 lanes x a power of two): the whole stream equals the oracle's."""
+    import zsc_amd
+    bufs = [corpus.make_buffer("random" if n % 2 else "text", n, n)
+            for n in (0, 1, 15, 16, 17, 1023, 1024, 1025, 1040, 4097, 65535, 65536, 65537, 131073, 300001)]
+    rc, outs, stats = zsc_amd.compress_batch(bufs, level=6, window_bits=31)
+    assert rc == 0 and all(s == 0 for s in stats)
+    for b, o in zip(bufs, outs):
+        assert o == oracle.compress(b, 6, window_bits=31)[1], len(b)

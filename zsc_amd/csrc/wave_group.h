@@ -16,7 +16,7 @@
  * instructions per input byte where one 64-lane parser executes 240: DESIGN.md section 5).
  *
  * On the host (tests/emu) a group is always the whole emulated wave; building that emulation
- * with 16-lane waves (libzsc_emu16.so) runs group code at the width it has on the GPU.
+ * with 16-lane waves runs group code at the width it has on the GPU.
  */
 #undef GRP
 #undef GROUPS_PER_WAVE

@@ -13,13 +13,52 @@
 #include "zsc/zsc_conf_private.h"
 #include "zsc_hip.h"
 
-/* sizeof(deflate_state) / sizeof(inflate_state) of the reference on an LP64 host
- * (reference include/zsc/deflate.h:119-290, include/zsc/inflate.h:106-149; both are
- * below the Z_*_STATE_SIZE ceilings of zlib_types_pub.h:94,112).  The minimum work
- * sizes the reference demands derive from them; tests/test_api_host.py checks the
- * results against the compiled reference. */
-#define ZSC_DEFLATE_STATE_BYTES 5920u
-#define ZSC_INFLATE_STATE_BYTES 7152u
+/* sizeof(deflate_state) / sizeof(inflate_state) of the reference, which its minimum work sizes
+ * derive from (reference src/deflate.c:857-902, src/inflate.c:249-276).  They depend on the
+ * ABI (pointer size, alignment, enum width), so they are COMPUTED: the two structs below
+ * restate the reference's private state member for member as far as layout goes -- same
+ * sequence of types (include/zsc/deflate.h:119-290, include/zsc/inflate.h:106-149,
+ * inftrees.h:57-61), runs of equally sized scalars written as arrays -- and the compiler
+ * does the rest.  On LP64 they come to 5 920 and 7 152 bytes, what the compiled reference
+ * reports (tests/test_api_host.py); both stay below the Z_*_STATE_SIZE ceilings of
+ * zlib_types_pub.h. */
+typedef enum { ZSC_LAYOUT_ENUM_0 = 0 } zsc_layout_enum; /* an enum as wide as the reference's own */
+typedef struct { U16 fc, dl; } zsc_layout_ct;            /* ct_data: two unions of U16 */
+typedef struct { void *dyn_tree; I32 max_code; const void *stat_desc; } zsc_layout_tree_desc;
+struct zsc_layout_deflate_state {
+    void *strm; I32 status;
+    U8 *pending_buf; U32 pending_buf_size;
+    U8 *pending_out; U32 pending_and_wrap[2];
+    void *gzhead; U32 gzindex; ZlibMethod method; ZlibFlush last_flush;
+    U32 w_size_bits_mask[3];
+    U8 *window; U32 window_size;
+    U16 *prev; U16 *head;
+    U32 hash_and_match_state[16]; /* ins_h .. max_lazy_match, level */
+    ZlibStrategy strategy; U32 good_match; I32 nice_match;
+    zsc_layout_ct dyn_ltree[2 * 286 + 1], dyn_dtree[2 * 30 + 1], bl_tree[2 * 19 + 1];
+    zsc_layout_tree_desc l_desc, d_desc, bl_desc;
+    U16 bl_count[15 + 1];
+    I32 heap[2 * 286 + 1], heap_len, heap_max;
+    U8 depth[2 * 286 + 1];
+    U8 *l_buf; U32 lit_bufsize, last_lit;
+    U16 *d_buf; U32 opt_static_matches_insert[4];
+    U16 bi_buf; I32 bi_valid; U32 high_water;
+};
+typedef struct { U8 op, bits; U16 val; } zsc_layout_code;
+struct zsc_layout_inflate_state {
+    void *strm; zsc_layout_enum mode; I32 last_wrap_havedict_flags[4]; U32 dmax_check_total[3];
+    void *head; U32 wbits_wsize_whave_wnext[4];
+    U8 *window; U32 hold_bits_length_offset_extra[5];
+    const zsc_layout_code *lencode, *distcode; U32 lenbits_distbits_ncode_nlen_ndist_have[6];
+    zsc_layout_code *next;
+    U16 lens[320], work[288];
+    zsc_layout_code codes[852 + 592];
+    I32 sane, back; U32 was;
+};
+#define ZSC_DEFLATE_STATE_BYTES ((U32)sizeof(struct zsc_layout_deflate_state))
+#define ZSC_INFLATE_STATE_BYTES ((U32)sizeof(struct zsc_layout_inflate_state))
+ZSC_COMPILE_ASSERT(sizeof(struct zsc_layout_deflate_state) <= Z_DEFLATE_STATE_SIZE, deflate_state_fits_its_ceiling);
+ZSC_COMPILE_ASSERT(sizeof(struct zsc_layout_inflate_state) <= Z_INFLATE_STATE_SIZE, inflate_state_fits_its_ceiling);
 
 /* ---- sizing helpers -------------------------------------------------------- */
 
