@@ -81,6 +81,9 @@
 #ifndef SL_USE_BULK
 #define SL_USE_BULK 0
 #endif
+#ifndef SL_TAIL
+#define SL_TAIL 8u /* bulk slots are for the tail of a super-step: when at most this many lanes of the wave still parse */
+#endif
 #ifndef SL_BULK_MIN
 #define SL_BULK_MIN 16u /* a chain with at least this many candidates left (and its first block done) is walked 64 at a time */
 #endif
@@ -148,6 +151,7 @@ typedef struct {
     LANEVAR(uint32_t, pmj_at);
     LANEVAR(uint32_t, hvy_ok); /* the search has not been considered for the whole wave yet */
     LANEVAR(uint32_t, bslot);  /* the bulk slot that works for this lane, or SL_NONE */
+    LANEVAR(uint32_t, nbulk);  /* (the same in every lane) bulk slots in use */
     LANEVAR(uint32_t, bk0);    /* the entries of the bulk slots: lane l holds entry l of each */
     LANEVAR(uint32_t, bk1);
     LANEVAR(uint32_t, bk2);
@@ -740,6 +744,7 @@ DEV void sl_parse_start(const LzJob &job, SlLds *lds, int w, SlWave &ws)
         LV(ws.pm1_at) = LV(ws.pmj_at) = SL_NONE;
         LV(ws.hvy_ok) = 0;
         LV(ws.bslot) = SL_NONE;
+        LV(ws.nbulk) = 0;
         LV(ws.bk0) = LV(ws.bk1) = LV(ws.bk2) = LV(ws.bk3) = 0;
         LV(ws.bk4) = LV(ws.bk5) = LV(ws.bk6) = LV(ws.bk7) = 0;
         if (s == 0) {
@@ -900,6 +905,9 @@ DEV int sl_parse_round(const LzJob &job, SlLds *lds, const SlScratch &scr, int w
      * last step waited for them -- nothing here waits for a load issued in this round) */
     SlStage *sg = &lds->stage[w];
 #if SL_USE_BULK
+    const int tail = (uint32_t)POPC64(m_adv | m_wait | m_busy | m_hvy) <= SL_TAIL;
+    uint32_t nbulk = UNI(LV_UNIFORM(ws.nbulk));
+    if (nbulk != 0u) {
     ON_LANE0
     {
         for (uint32_t i = 0; i < SL_NBULK; i++)
@@ -915,6 +923,8 @@ DEV int sl_parse_round(const LzJob &job, SlLds *lds, const SlScratch &scr, int w
     SL_BULK_EVAL(6, ws.bk6);
     SL_BULK_EVAL(7, ws.bk7);
     WAVE_SYNC();
+    nbulk = 0; /* a slot serves one round */
+    }
 #endif
     /* 1: the advance block, for the lanes at a loop top -- when enough of them are */
     if ((m_adv != 0 && (POPC64(m_adv) >= SL_ADV_MIN || m_old != 0 || m_busy == 0)) || (m_wait != 0 && m_busy == 0 && m_adv == 0)) {
@@ -934,7 +944,7 @@ DEV int sl_parse_round(const LzJob &job, SlLds *lds, const SlScratch &scr, int w
     /* 2: ask for what a lane looks at next: 64 entries at once for a few lanes with long chains
      * (bulk slots), for the others the block of eight behind the one they are working through */
 #if SL_USE_BULK
-    {
+    if (tail) {
         LANEVAR(int, f_want);
         LANEVAR(int, f_long);
         FOR_LANES
@@ -965,7 +975,9 @@ DEV int sl_parse_round(const LzJob &job, SlLds *lds, const SlScratch &scr, int w
                 }
             }
             WAVE_SYNC();
+            nbulk++;
         }
+        if (nbulk != 0u) {
         SL_BULK_LOAD(0, ws.bk0);
         SL_BULK_LOAD(1, ws.bk1);
         SL_BULK_LOAD(2, ws.bk2);
@@ -974,7 +986,9 @@ DEV int sl_parse_round(const LzJob &job, SlLds *lds, const SlScratch &scr, int w
         SL_BULK_LOAD(5, ws.bk5);
         SL_BULK_LOAD(6, ws.bk6);
         SL_BULK_LOAD(7, ws.bk7);
+        }
     }
+    FOR_LANES { LV(ws.nbulk) = nbulk; }
 #else
     (void)sg;
 #endif

@@ -40,6 +40,7 @@
 #define LDS_DECL(T, name, n) T name[n]
 #define LANEVAR(T, name) T name[WAVE]
 #define LV(name) name[_lane]
+#define LV_UNIFORM(name) name[0] /* a LANEVAR that holds the same value in every lane, read outside FOR_LANES */
 #define FOR_LANES for (int _lane = 0; _lane < WAVE; ++_lane)
 #define LANE (_lane)
 #define ON_LANE0
@@ -132,6 +133,7 @@ static inline uint32_t emu_brev32(uint32_t v)
 #define LDS_DECL(T, name, n) __shared__ T name[n]
 #define LANEVAR(T, name) T name
 #define LV(name) name
+#define LV_UNIFORM(name) name
 #define FOR_LANES
 #define LANE ((int)(threadIdx.x & 63))
 #define ON_LANE0 if ((threadIdx.x & 63) == 0)
