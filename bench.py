@@ -260,6 +260,10 @@ def main() -> None:
     ap.add_argument("--inflate-streams", type=int, default=1048576,
                     help="gzip members of the inflate section (BASELINE config 4; 0: skip)")
     ap.add_argument("--inflate-distinct", type=int, default=2048, help="distinct gzip members among them")
+    ap.add_argument("--stage-on-root", action="store_true",
+                    help="N > 1 only: the whole job's input is staged in GPU 0's memory and scattered to the "
+                         "ranks point to point, the streams are gathered back (BASELINE config 5's wording; "
+                         "reported beside the headline, never part of it)")
     ap.add_argument("--levels-64k", type=int, default=16384,
                     help="64 KiB buffers of the level 1/6/9 section (BASELINE config 3; 0: skip)")
     ap.add_argument("--with-inflate", action="store_true",
@@ -313,6 +317,27 @@ def main() -> None:
     d_in[:plan.in_bytes - 64] = d_period.repeat(reps)[:plan.in_bytes - 64]
     d_out = torch.empty(plan.out_bytes, dtype=torch.uint8, device=dev)
     del d_period
+    staged = None
+    if args.stage_on_root and world > 1:
+        # every rank owns the same number of sets, so every rank's plan has the same layout: the root
+        # holds `world` images of it (here: copies of its own, the payload is what matters), scatters
+        # them, and gets the output images back after the timed steps
+        nb = torch.tensor([plan.in_bytes, plan.out_bytes], dtype=torch.int64, device=dev)
+        lo, hi = nb.clone(), nb.clone()
+        dist.all_reduce(lo, op=dist.ReduceOp.MIN)
+        dist.all_reduce(hi, op=dist.ReduceOp.MAX)
+        if not bool((lo == hi).all()):
+            raise SystemExit("--stage-on-root needs equal shards")
+        in_ranges = [(r * plan.in_bytes, (r + 1) * plan.in_bytes) for r in range(world)]
+        full = d_in.repeat(world) if rank == 0 else None
+        fence_t0 = time.perf_counter()
+        torch.cuda.synchronize()
+        dist.barrier()
+        d_in = sharding.scatter_payload(full, in_ranges, rank, world, device=dev)
+        torch.cuda.synchronize()
+        dist.barrier()
+        staged = {"scatter_ms": round((time.perf_counter() - fence_t0) * 1e3, 3), "bytes_per_rank": plan.in_bytes}
+        del full
     in_bytes_rank = sum(my_lens)
     stream = torch.cuda.current_stream().cuda_stream
 
@@ -381,6 +406,18 @@ def main() -> None:
         raise SystemExit(f"rank {rank}: a replica's stream differs from its first copy")
     checked = {"distinct_buffers_vs_oracle": nver, "of": nper, "replicas_equal_on_device": bool(replicas_ok),
                "buffers": len(my_lens)}
+    if staged is not None:
+        out_ranges = [(r * plan.out_bytes, (r + 1) * plan.out_bytes) for r in range(world)]
+        torch.cuda.synchronize()
+        dist.barrier()
+        t1 = time.perf_counter()
+        gathered = sharding.gather_payload(d_out, out_ranges, rank, world, device=dev)
+        torch.cuda.synchronize()
+        dist.barrier()
+        staged["gather_ms"] = round((time.perf_counter() - t1) * 1e3, 3)
+        staged["note"] = ("input images scattered from / output images gathered to GPU 0 with point-to-point "
+                          "sends (zsc_amd.sharding); outside the timed steps")
+        del gathered
 
     # ---- inflate of the streams just produced (reported beside the headline, not part of it)
     inflate_info = None
@@ -480,6 +517,8 @@ def main() -> None:
                 line["roofline"]["traffic_note"] = pmc["note"]
         except Exception:
             pass
+        if staged is not None:
+            line["staged_on_root"] = staged
         if inflate_info:
             line["inflate_of_these_streams"] = inflate_info
         if sections_info:

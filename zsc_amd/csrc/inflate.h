@@ -49,7 +49,7 @@ typedef struct {
     InfCodeT<32> dist;
     InfCodeT<20> cl;
     uint16_t lens[320];
-    uint8_t stage[INF_STAGE + 320]; /* output not yet stored: [flushed, pos) */
+    uint8_t stage[INF_STAGE + 8];   /* output not yet stored: [flushed, pos), indexed modulo INF_STAGE */
     uint32_t ckx[64];               /* exchange area of the CRC routine */
     uint32_t (*cktab)[256];         /* its byte-loop table (1 KiB), shared by the streams of a wave */
 } InfLds;

@@ -61,3 +61,58 @@ def gather_sizes(local_sizes: Sequence[int], total: int, begin: int, rank: int, 
     if world > 1:
         dist.all_reduce(full, op=dist.ReduceOp.SUM)
     return [int(x) for x in full.cpu()]
+
+
+# ---- root-staged variant (SURVEY 8e "north-star variant", BASELINE config 5) ------------------
+#
+# The whole batch lies in GPU 0's memory; every other rank receives ITS byte range of it and sends
+# its streams back.  Point-to-point from / to the root (on the GPU box: one ncclGroup of
+# ncclSend / ncclRecv, which uses all of the root's xGMI links at once -- not a ring), payload as
+# plain bytes, ranges cut where buffers start.  Only bench.py --stage-on-root and the gloo test use
+# this; the default path never moves payload between GPUs.
+
+def scatter_payload(full, byte_ranges: Sequence[Tuple[int, int]], rank: int, world: int, device="cpu"):
+    """`full`: the staged batch on rank 0 (uint8 tensor; None elsewhere).  Returns this rank's
+    slice [byte_ranges[rank]) as a tensor on `device`."""
+    import torch
+    import torch.distributed as dist
+
+    b, e = byte_ranges[rank]
+    if world == 1:
+        return full[b:e]
+    mine = torch.empty(e - b, dtype=torch.uint8, device=device)
+    if rank == 0:
+        mine.copy_(full[b:e])
+        ops = [dist.P2POp(dist.isend, full[rb:re].contiguous(), r)
+               for r, (rb, re) in enumerate(byte_ranges) if r != 0 and re > rb]
+    else:
+        ops = [dist.P2POp(dist.irecv, mine, 0)] if e > b else []
+    if ops:
+        for w in dist.batch_isend_irecv(ops):
+            w.wait()
+    return mine
+
+
+def gather_payload(local, byte_ranges: Sequence[Tuple[int, int]], rank: int, world: int, device="cpu"):
+    """The reverse: every rank's `local` bytes (its streams, laid out back to back as the root
+    expects them) arrive at byte_ranges[rank] of one tensor on rank 0, which is returned there
+    (None elsewhere).  len(local) must equal the rank's range."""
+    import torch
+    import torch.distributed as dist
+
+    b, e = byte_ranges[rank]
+    assert local.numel() == e - b, (local.numel(), b, e)
+    if world == 1:
+        return local
+    full = None
+    if rank == 0:
+        full = torch.empty(max(re for _, re in byte_ranges), dtype=torch.uint8, device=device)
+        full[b:e] = local
+        ops = [dist.P2POp(dist.irecv, full[rb:re], r)
+               for r, (rb, re) in enumerate(byte_ranges) if r != 0 and re > rb]
+    else:
+        ops = [dist.P2POp(dist.isend, local.contiguous(), 0)] if e > b else []
+    if ops:
+        for w in dist.batch_isend_irecv(ops):
+            w.wait()
+    return full
