@@ -4,7 +4,7 @@ batched call; the oracle runs on the host cores beside it.  usage: soak.py SECON
 import os, sys, time, random
 from concurrent.futures import ProcessPoolExecutor
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-from zsc_amd import corpus
+from zsc_amd import corpus  # (loads libzsc_hip.so but makes no HIP call: the GPU is untouched until zsc_hip_init)
 
 KINDS = ("text", "bitmap", "table", "random", "zero", "runs", "token", "object")
 _o = None
@@ -35,6 +35,12 @@ def inflate_job(job):
 def main():
     budget = float(sys.argv[1]) if len(sys.argv) > 1 else 60.0
     seed = int(sys.argv[2]) if len(sys.argv) > 2 else 1
+    # the oracle's worker processes are forked and warmed up BEFORE this process touches the GPU:
+    # a HIP-initialised process must not be forked (its runtime threads, locks and KFD state would
+    # be inherited half-alive)
+    workers = min(16, os.cpu_count() or 1)
+    pool = ProcessPoolExecutor(max_workers=workers)
+    list(pool.map(inflate_job, [(b"", 1, 15)] * (4 * workers), chunksize=1))
     import zsc_amd as z
     from oracle.oracle_py import Oracle
     o = Oracle()
@@ -42,7 +48,6 @@ def main():
     rnd = random.Random(seed)
     t0 = time.time()
     total = streams = bad = batches = 0
-    pool = ProcessPoolExecutor(max_workers=min(16, os.cpu_count() or 1))
     while time.time() - t0 < budget:
         lvl = rnd.choice([1, 2, 3, 4, 5, 6, 6, 6, 7, 8, 9])
         wb = rnd.choice([15, 15, 15, 31, -15, 14, 12, 10, 9, -9, 25])
