@@ -200,24 +200,49 @@ DEV void sg_phase_begin(const LzJob &job, SgLds *lds, int w)
             pv_at = p;                                                                        \
             FOR_GLANES { LV(pv) = lds_u32(lds->ring, lz_ridx<L>(st, p + 4u * (uint32_t)GLANE)); } \
         }                                                                                     \
-        (LEN) = cap;                                                                          \
-        /* 4 GRP bytes per step (the first one against the string at p held in registers); what a \
-         * step reads past cap is cut off below */                                            \
-        for (uint32_t _o = 0; _o < cap; _o += 4u * GRP) {                                     \
+        if (4u * GRP >= 256u) {                                                               \
+            /* a 64-lane group: the first 256 bytes in one step, against the string at p held \
+             * in registers, then the last two bytes one by one */                            \
             LANEVAR(uint32_t, _diff);                                                         \
             LANEVAR(int, _differs);                                                           \
             FOR_GLANES                                                                        \
             {                                                                                 \
-                const uint32_t _pw = _o == 0u ? LV(pv)                                        \
-                                              : lds_u32(lds->ring, lz_ridx<L>(st, p + _o + 4u * (uint32_t)GLANE)); \
-                LV(_diff) = lds_u32(lds->ring, lz_ridx<L>(st, (QJ) + _o + 4u * (uint32_t)GLANE)) ^ _pw; \
+                LV(_diff) = lds_u32(lds->ring, lz_ridx<L>(st, (QJ) + 4u * (uint32_t)GLANE)) ^ LV(pv); \
                 LV(_differs) = LV(_diff) != 0;                                                \
             }                                                                                 \
             const uint64_t _dm = GBALLOT(_differs);                                           \
             if (_dm != 0) {                                                                   \
                 const int _f = CTZ64(_dm);                                                    \
-                (LEN) = _o + 4u * (uint32_t)_f + ((uint32_t)CTZ32(GREADLANE(_diff, _f)) >> 3); \
-                break;                                                                        \
+                (LEN) = 4u * (uint32_t)_f + ((uint32_t)CTZ32(GREADLANE(_diff, _f)) >> 3);     \
+            } else {                                                                          \
+                (LEN) = 256;                                                                  \
+                if (cap > 256 && GUNI(lds->ring[lz_ridx<L>(st, (QJ) + 256)]) ==               \
+                                     GUNI(lds->ring[lz_ridx<L>(st, p + 256)])) {              \
+                    (LEN) = 257;                                                              \
+                    if (cap > 257 && GUNI(lds->ring[lz_ridx<L>(st, (QJ) + 257)]) ==           \
+                                         GUNI(lds->ring[lz_ridx<L>(st, p + 257)]))            \
+                        (LEN) = 258;                                                          \
+                }                                                                             \
+            }                                                                                 \
+        } else {                                                                              \
+            /* a narrower group: 4 GRP bytes per step; what is read past cap is cut off below */ \
+            (LEN) = cap;                                                                      \
+            for (uint32_t _o = 0; _o < cap; _o += 4u * GRP) {                                 \
+                LANEVAR(uint32_t, _diff);                                                     \
+                LANEVAR(int, _differs);                                                       \
+                FOR_GLANES                                                                    \
+                {                                                                             \
+                    const uint32_t _pw = _o == 0u ? LV(pv)                                    \
+                                                  : lds_u32(lds->ring, lz_ridx<L>(st, p + _o + 4u * (uint32_t)GLANE)); \
+                    LV(_diff) = lds_u32(lds->ring, lz_ridx<L>(st, (QJ) + _o + 4u * (uint32_t)GLANE)) ^ _pw; \
+                    LV(_differs) = LV(_diff) != 0;                                            \
+                }                                                                             \
+                const uint64_t _dm = GBALLOT(_differs);                                       \
+                if (_dm != 0) {                                                               \
+                    const int _f = CTZ64(_dm);                                                \
+                    (LEN) = _o + 4u * (uint32_t)_f + ((uint32_t)CTZ32(GREADLANE(_diff, _f)) >> 3); \
+                    break;                                                                    \
+                }                                                                             \
             }                                                                                 \
         }                                                                                     \
         if ((LEN) > cap)                                                                      \
