@@ -112,6 +112,7 @@ typedef struct {
 #define INF_CK(name) ck_##name
 #endif
 #define INF_CHUNK (4u * GRP) /* input bytes held across the lanes of the group */
+#define INF_SLOTS (GRP >= 16 ? 1 : 2) /* code lengths a lane tests: l, and l + GRP in a group of 8 */
 
 /* build a canonical decoder from code lengths.  kind 0: code-length code, 1: literal/
  * length, 2: distance.  Returns 0, or -1 for an invalid set (src/inftrees.c:168-177). */
@@ -404,17 +405,22 @@ DEV int inflate_stream(const InfJob &job, InfLds *lds, InfResult *res, InfResume
         const uint32_t _peek = (uint32_t)br.hold & 0x7fffu;                                   \
         const uint32_t _r = BREV32(_peek) >> 17; /* the 15 bits MSB first */                  \
         LANEVAR(int, _hit);                                                                   \
+        LANEVAR(int, _hit2);                                                                  \
         FOR_GLANES                                                                             \
         {                                                                                     \
-            int _l = GLANE;                                                                    \
-            int _ok = 0;                                                                      \
-            if (_l >= 1 && _l <= (int)(C)->max_len) {                                         \
-                uint32_t _c = _r >> (15 - _l);                                                \
-                _ok = (uint32_t)(_c - (C)->first[_l]) < (uint32_t)(C)->count[_l];             \
+            /* lane l tests the code lengths l and (in a group of fewer than 16 lanes) l + GRP */ \
+            int _ok[2] = {0, 0};                                                              \
+            for (int _k = 0; _k < INF_SLOTS; _k++) {                                          \
+                const int _l = GLANE + _k * (int)GRP;                                         \
+                if (_l >= 1 && _l <= (int)(C)->max_len) {                                     \
+                    uint32_t _c = _r >> (15 - _l);                                            \
+                    _ok[_k] = (uint32_t)(_c - (C)->first[_l]) < (uint32_t)(C)->count[_l];     \
+                }                                                                             \
             }                                                                                 \
-            LV(_hit) = _ok;                                                                   \
+            LV(_hit) = _ok[0];                                                                \
+            LV(_hit2) = _ok[1];                                                               \
         }                                                                                     \
-        const uint64_t _m = GBALLOT(_hit);                                                     \
+        const uint64_t _m = GBALLOT(_hit) | (INF_SLOTS > 1 ? GBALLOT(_hit2) << (GRP & 63u) : 0ull); \
         if (_m == 0) {                                                                        \
             /* no code matches: only possible for the lone 1-bit code (incomplete set) */     \
             INF_NEED((C)->max_len);                                                           \
@@ -440,7 +446,7 @@ DEV int inflate_stream(const InfJob &job, InfLds *lds, InfResult *res, InfResume
 /* The same for the two codes of the symbol loop, with each length's first code, count and
  * symbol offset held by lane `length` in registers (FC = first | count << 16, OF = offs):
  * one LDS read per symbol instead of five. */
-#define INF_DECODE_R(C, FC, OF, MAXLEN, EMPTY, OUTSYM)                                         \
+#define INF_DECODE_R(C, FC, OF, FC2, OF2, MAXLEN, EMPTY, OUTSYM)                               \
     do {                                                                                      \
         if (br.bits < 15)                                                                     \
             INF_REFILL();                                                                     \
@@ -455,14 +461,19 @@ DEV int inflate_stream(const InfJob &job, InfLds *lds, InfResult *res, InfResume
         const uint32_t _peek = (uint32_t)br.hold & 0x7fffu;                                   \
         const uint32_t _r = BREV32(_peek) >> 17; /* the 15 bits MSB first */                  \
         LANEVAR(int, _hit);                                                                   \
+        LANEVAR(int, _hit2);                                                                  \
         FOR_GLANES                                                                             \
         {                                                                                     \
             const uint32_t _l = (uint32_t)GLANE;                                               \
             const uint32_t _c = _r >> ((15u - _l) & 31u);                                     \
             LV(_hit) = _l >= 1u && _l <= (MAXLEN) &&                                          \
                        (uint32_t)(_c - (LV(FC) & 0xffffu)) < (LV(FC) >> 16);                  \
+            const uint32_t _l2 = _l + GRP;                                                    \
+            const uint32_t _c2 = _r >> ((15u - _l2) & 31u);                                   \
+            LV(_hit2) = INF_SLOTS > 1 && _l2 <= (MAXLEN) &&                                   \
+                        (uint32_t)(_c2 - (LV(FC2) & 0xffffu)) < (LV(FC2) >> 16);              \
         }                                                                                     \
-        const uint64_t _m = GBALLOT(_hit);                                                     \
+        const uint64_t _m = GBALLOT(_hit) | (INF_SLOTS > 1 ? GBALLOT(_hit2) << (GRP & 63u) : 0ull); \
         if (_m == 0) {                                                                        \
             INF_NEED(MAXLEN);                                                                 \
             uint32_t _d;                                                                      \
@@ -478,7 +489,9 @@ DEV int inflate_stream(const InfJob &job, InfLds *lds, InfResult *res, InfResume
             goto done;                                                                        \
         }                                                                                     \
         const uint32_t _code = _r >> (15 - _len);                                             \
-        (OUTSYM) = (int)GUNI((C)->sym[GREADLANE(OF, _len) + (_code - (GREADLANE(FC, _len) & 0xffffu))]); \
+        const uint32_t _ol = (INF_SLOTS > 1 && _len >= GRP) ? GREADLANE(OF2, _len - GRP) : GREADLANE(OF, _len); \
+        const uint32_t _fl = (INF_SLOTS > 1 && _len >= GRP) ? GREADLANE(FC2, _len - GRP) : GREADLANE(FC, _len); \
+        (OUTSYM) = (int)GUNI((C)->sym[_ol + (_code - (_fl & 0xffffu))]);                      \
         br.hold >>= _len;                                                                     \
         br.bits -= _len;                                                                      \
         br.used += _len;                                                                      \
@@ -724,19 +737,27 @@ DEV int inflate_stream(const InfJob &job, InfLds *lds, InfResult *res, InfResume
             LANEVAR(uint32_t, lof);
             LANEVAR(uint32_t, dfc);
             LANEVAR(uint32_t, dof);
+            LANEVAR(uint32_t, lfc2); /* (groups of fewer than 16 lanes: the lengths GLANE + GRP) */
+            LANEVAR(uint32_t, lof2);
+            LANEVAR(uint32_t, dfc2);
+            LANEVAR(uint32_t, dof2);
             FOR_GLANES
             {
-                const int l = GLANE & 15;
+                const int l = GLANE & 15, l2 = (GLANE + (int)GRP) & 15;
                 LV(lfc) = (uint32_t)lds->lit.first[l] | ((uint32_t)lds->lit.count[l] << 16);
                 LV(lof) = lds->lit.offs[l];
                 LV(dfc) = (uint32_t)lds->dist.first[l] | ((uint32_t)lds->dist.count[l] << 16);
                 LV(dof) = lds->dist.offs[l];
+                LV(lfc2) = (uint32_t)lds->lit.first[l2] | ((uint32_t)lds->lit.count[l2] << 16);
+                LV(lof2) = lds->lit.offs[l2];
+                LV(dfc2) = (uint32_t)lds->dist.first[l2] | ((uint32_t)lds->dist.count[l2] << 16);
+                LV(dof2) = lds->dist.offs[l2];
             }
             const uint32_t lmax = GUNI(lds->lit.max_len), lempty = GUNI(lds->lit.empty);
             const uint32_t dmaxlen = GUNI(lds->dist.max_len), dempty = GUNI(lds->dist.empty);
             for (;;) {
                 int sym;
-                INF_DECODE_R(&lds->lit, lfc, lof, lmax, lempty, sym);
+                INF_DECODE_R(&lds->lit, lfc, lof, lfc2, lof2, lmax, lempty, sym);
                 if (sym == -2)
                     INF_BAD;
                 if (sym < 256) {
@@ -761,7 +782,7 @@ DEV int inflate_stream(const InfJob &job, InfLds *lds, InfResult *res, InfResume
                 INF_TAKE(ex, xb);
                 len = c < 8 ? c + 3u : c == 28 ? 258u : ((4u + ((c - 4u) & 3u)) << ((c - 4u) >> 2)) + 3u + ex;
                 int ds;
-                INF_DECODE_R(&lds->dist, dfc, dof, dmaxlen, dempty, ds);
+                INF_DECODE_R(&lds->dist, dfc, dof, dfc2, dof2, dmaxlen, dempty, ds);
                 if (ds < 0 || ds > 29)
                     INF_BAD;
                 xb = ds < 4 ? 0u : ((uint32_t)ds >> 1) - 1u;

@@ -60,7 +60,7 @@
 DEV uint64_t group_sum_u64(uint64_t v)
 {
 #pragma unroll
-    for (int d = 8; d >= 1; d >>= 1) /* (groups of 16 lanes) */
+    for (int d = ZSC_GROUP / 2; d >= 1; d >>= 1) /* (every group code in one source uses the same width) */
         v += __shfl_xor(v, d);
     return v;
 }
