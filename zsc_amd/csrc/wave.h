@@ -40,6 +40,9 @@
 #define LDS_DECL(T, name, n) T name[n]
 #define LANEVAR(T, name) T name[WAVE]
 #define LV(name) name[_lane]
+#define UNROLL_FULL
+#define LANEARR(T, name, n) T name[n][WAVE] /* n values per lane, kept in registers on the GPU: constant indices only */
+#define LVA(name, k) name[k][_lane]
 #define LV_UNIFORM(name) name[0] /* a LANEVAR that holds the same value in every lane, read outside FOR_LANES */
 #define FOR_LANES for (int _lane = 0; _lane < WAVE; ++_lane)
 #define LANE (_lane)
@@ -133,6 +136,9 @@ static inline uint32_t emu_brev32(uint32_t v)
 #define LDS_DECL(T, name, n) __shared__ T name[n]
 #define LANEVAR(T, name) T name
 #define LV(name) name
+#define UNROLL_FULL _Pragma("unroll")
+#define LANEARR(T, name, n) T name[n]
+#define LVA(name, k) name[k]
 #define LV_UNIFORM(name) name
 #define FOR_LANES
 #define LANE ((int)(threadIdx.x & 63))

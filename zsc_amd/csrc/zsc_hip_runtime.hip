@@ -148,10 +148,11 @@ __global__ __launch_bounds__(256) void k_store(const uint8_t *__restrict__ in,
 __global__ __launch_bounds__(HS_WAVES * 64) void k_hash_sort(
     const uint8_t *__restrict__ in, const ZdBuf *__restrict__ bufs,
     const uint32_t *__restrict__ tile_owner, uint32_t *__restrict__ sorted,
-    uint32_t *__restrict__ tmp, uint16_t *__restrict__ rank, uint16_t *__restrict__ dir,
+    uint16_t *__restrict__ rank, uint16_t *__restrict__ dir,
     uint16_t *__restrict__ sorted16, uint32_t ntiles)
 {
     __shared__ HsLds lds;
+    HsRegs regs;
     const uint32_t tile = blockIdx.x;
     if (tile >= ntiles)
         return;
@@ -166,17 +167,19 @@ __global__ __launch_bounds__(HS_WAVES * 64) void k_hash_sort(
     job.sorted = sorted + (uint64_t)tile * ZD_TILE;
     job.sorted16 = sorted16 ? sorted16 + (uint64_t)tile * ZD_TILE : nullptr;
     job.meta = nullptr;
-    job.tmp = tmp + (uint64_t)tile * ZD_TILE;
     job.rank = rank + buf.rank_off;
     job.dir = dir + (uint64_t)tile * ZD_DIR_STRIDE;
     job.dir_prev = nullptr;
     job.hib = nullptr;
     job.cnt = nullptr;
     const int w = (int)(threadIdx.x >> 6);
-    for (int phase = 0; phase < HS_PHASES; phase++) {
-        hash_sort_phase(job, &lds, w, phase);
-        __syncthreads();
-    }
+#define HS_PHASE(p)                               \
+    hash_sort_phase(job, &lds, &regs, w, p);      \
+    __syncthreads()
+    HS_PHASE(0); HS_PHASE(1); HS_PHASE(2); HS_PHASE(3); HS_PHASE(4); HS_PHASE(5);
+    HS_PHASE(6); HS_PHASE(7); HS_PHASE(8); HS_PHASE(9); HS_PHASE(10); HS_PHASE(11);
+    static_assert(HS_PHASES == 12, "phases of the tile sort");
+#undef HS_PHASE
 }
 
 /* kernel 1b: one workgroup per tile: chain lengths, and the link into the previous tile */
@@ -200,7 +203,6 @@ __global__ __launch_bounds__(HS_WAVES * 64) void k_link_prev(
     job.sorted = nullptr;
     job.sorted16 = nullptr;
     job.meta = meta ? meta + buf.rank_off : nullptr;
-    job.tmp = nullptr;
     job.rank = const_cast<uint16_t *>(rank) + buf.rank_off;
     job.dir = const_cast<uint16_t *>(dir) + (uint64_t)tile * ZD_DIR_STRIDE;
     job.dir_prev = t ? dir + (uint64_t)(tile - 1) * ZD_DIR_STRIDE : nullptr;
@@ -1291,7 +1293,7 @@ extern "C" ZlibReturn zsc_hip_deflate_plan_run(zsc_hip_deflate_plan *pl, const v
         const bool simple = pl->strategy == (uint32_t)Z_HUFFMAN_ONLY || pl->strategy == (uint32_t)Z_RLE;
         if (!simple) {
             hipLaunchKernelGGL(k_hash_sort, dim3(sb.ntiles), dim3(HS_WAVES * 64), 0, st, in, bufs,
-                               (const uint32_t *)sb.d_tile_owner.p, sorted, tmp_syms, rank, dir,
+                               (const uint32_t *)sb.d_tile_owner.p, sorted, rank, dir,
                                (uint16_t *)pl->d_sorted16.p, sb.ntiles);
             hipLaunchKernelGGL(k_link_prev, dim3(sb.ntiles), dim3(HS_WAVES * 64), 0, st, in, bufs,
                                (const uint32_t *)sb.d_tile_owner.p, (const uint16_t *)dir,
