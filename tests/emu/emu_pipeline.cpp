@@ -102,6 +102,7 @@ static void build_chains(EmuChains &c, const uint8_t *src, uint32_t n)
         tile.start = t * ZD_TILE;
         tile.m = owners > tile.start ? (owners - tile.start < ZD_TILE ? owners - tile.start : ZD_TILE) : 0;
         tile.sorted = c.sorted.data() + (size_t)t * ZD_TILE;
+        tile.tmp = c.tmp.data() + (size_t)t * ZD_TILE;
         tile.rank = c.rank.data();
         tile.dir = c.dir.data() + (size_t)t * ZD_DIR_STRIDE;
         tile.dir_prev = nullptr;
@@ -109,11 +110,10 @@ static void build_chains(EmuChains &c, const uint8_t *src, uint32_t n)
         tile.cnt = nullptr;
         tile.sorted16 = c.sorted16.data() + (size_t)t * ZD_TILE;
         tile.meta = nullptr;
-        static thread_local HsLds lds;
-        static thread_local HsRegs regs[HS_WAVES];
+        HsLds lds;
         for (int ph = 0; ph < HS_PHASES; ph++)
             for (int w = 0; w < HS_WAVES; w++)
-                hash_sort_phase(tile, &lds, &regs[w], w, ph);
+                hash_sort_phase(tile, &lds, w, ph);
     }
     for (uint32_t t = 0; t < c.ntiles; t++) { /* kernel 1b */
         HsTile tile;

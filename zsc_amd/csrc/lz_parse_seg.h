@@ -50,6 +50,14 @@
 #ifndef SG_SPAN
 #define SG_SPAN 8192u               /* positions per super-step */
 #endif
+/* SG_ENT16=1: chain entries read as 16-bit positions (sorted16) instead of position | hash << 16
+ * (sorted) -- the parser never looks at the hash half, and a 64-candidate load is one 128-byte
+ * line.  Measured (x4096, level 6): the parse 2 847 -> 2 834 ms, but the sort's third scattered
+ * store costs 28 ms (233 -> 262 ms), and the sort itself needs the hash half (second pass,
+ * directory), so the 32-bit entries stay. */
+#ifndef SG_ENT16
+#define SG_ENT16 0
+#endif
 #ifndef SG_MIN_WAVES
 #define SG_MIN_WAVES 6 /* waves per SIMD the register allocation aims at (three workgroups per CU) */
 #endif
@@ -613,7 +621,11 @@ DEV void sg_parse_segment(const LzJob &job, SgLds *lds, const SgScratch &scr, ui
                 SG_COUNT(5, 1);
                 const int32_t hiA = (int32_t)(rh & 0xffffu) - 1, hiB = (int32_t)(rh >> 16);
                 const uint32_t tileA = p & ~ZD_TILE_MASK;
+#if SG_ENT16
+                const uint16_t *runA = job.sorted16 + (uint64_t)(p >> 15) * ZD_TILE;
+#else
                 const uint32_t *runA = job.sorted + (uint64_t)(p >> 15) * ZD_TILE;
+#endif
                 const uint32_t floor_pos = p - st.base > job.cfg.max_dist ? p - job.cfg.max_dist : st.base;
                 const uint32_t cap = look < 258u ? look : 258u;
                 const uint32_t nice = job.cfg.nice < look ? job.cfg.nice : look;

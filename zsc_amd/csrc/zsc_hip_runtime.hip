@@ -148,11 +148,10 @@ __global__ __launch_bounds__(256) void k_store(const uint8_t *__restrict__ in,
 __global__ __launch_bounds__(HS_WAVES * 64) void k_hash_sort(
     const uint8_t *__restrict__ in, const ZdBuf *__restrict__ bufs,
     const uint32_t *__restrict__ tile_owner, uint32_t *__restrict__ sorted,
-    uint16_t *__restrict__ rank, uint16_t *__restrict__ dir,
+    uint32_t *__restrict__ tmp, uint16_t *__restrict__ rank, uint16_t *__restrict__ dir,
     uint16_t *__restrict__ sorted16, uint32_t ntiles)
 {
     __shared__ HsLds lds;
-    HsRegs regs;
     const uint32_t tile = blockIdx.x;
     if (tile >= ntiles)
         return;
@@ -167,19 +166,17 @@ __global__ __launch_bounds__(HS_WAVES * 64) void k_hash_sort(
     job.sorted = sorted + (uint64_t)tile * ZD_TILE;
     job.sorted16 = sorted16 ? sorted16 + (uint64_t)tile * ZD_TILE : nullptr;
     job.meta = nullptr;
+    job.tmp = tmp + (uint64_t)tile * ZD_TILE;
     job.rank = rank + buf.rank_off;
     job.dir = dir + (uint64_t)tile * ZD_DIR_STRIDE;
     job.dir_prev = nullptr;
     job.hib = nullptr;
     job.cnt = nullptr;
     const int w = (int)(threadIdx.x >> 6);
-#define HS_PHASE(p)                               \
-    hash_sort_phase(job, &lds, &regs, w, p);      \
-    __syncthreads()
-    HS_PHASE(0); HS_PHASE(1); HS_PHASE(2); HS_PHASE(3); HS_PHASE(4); HS_PHASE(5);
-    HS_PHASE(6); HS_PHASE(7); HS_PHASE(8); HS_PHASE(9); HS_PHASE(10); HS_PHASE(11);
-    static_assert(HS_PHASES == 12, "phases of the tile sort");
-#undef HS_PHASE
+    for (int phase = 0; phase < HS_PHASES; phase++) {
+        hash_sort_phase(job, &lds, w, phase);
+        __syncthreads();
+    }
 }
 
 /* kernel 1b: one workgroup per tile: chain lengths, and the link into the previous tile */
@@ -203,6 +200,7 @@ __global__ __launch_bounds__(HS_WAVES * 64) void k_link_prev(
     job.sorted = nullptr;
     job.sorted16 = nullptr;
     job.meta = meta ? meta + buf.rank_off : nullptr;
+    job.tmp = nullptr;
     job.rank = const_cast<uint16_t *>(rank) + buf.rank_off;
     job.dir = const_cast<uint16_t *>(dir) + (uint64_t)tile * ZD_DIR_STRIDE;
     job.dir_prev = t ? dir + (uint64_t)(tile - 1) * ZD_DIR_STRIDE : nullptr;
@@ -264,6 +262,7 @@ __global__ __launch_bounds__(SG_W * 64, SG_MIN_WAVES) void k_parse_seg(const uin
                                                          const uint16_t *__restrict__ rank,
                                                          const uint16_t *__restrict__ hib,
                                                          const uint32_t *__restrict__ cnt,
+                                                         const uint16_t *__restrict__ sorted16,
                                                          uint32_t *__restrict__ syms,
                                                          ZdBlockRec *__restrict__ recs,
                                                          ZdParseOut *__restrict__ pout,
@@ -286,7 +285,7 @@ __global__ __launch_bounds__(SG_W * 64, SG_MIN_WAVES) void k_parse_seg(const uin
     job.rank = rank + buf.rank_off;
     job.hib = hib + buf.rank_off;
     job.cnt = cnt + buf.rank_off;
-    job.sorted16 = nullptr;
+    job.sorted16 = sorted16 ? sorted16 + (uint64_t)buf.tile0 * ZD_TILE : nullptr;
     job.meta = nullptr;
     job.syms = syms + buf.sym_off;
     job.blocks = recs + buf.blk0;
@@ -1220,8 +1219,10 @@ static ZlibReturn plan_create(zsc_hip_deflate_plan **plan_out, U32 count, const 
               pl->d_plans.ensure(max_slots * sizeof(ZdBlockPlan)) &&
               pl->d_pout.ensure(max_count * sizeof(ZdParseOut)) &&
               pl->d_res.ensure((uint64_t)std::max(1u, count) * sizeof(ZdResult));
+    if (ok && (pl->use_lane || (SG_ENT16 && max_seg != 0)))
+        ok = pl->d_sorted16.ensure(tile_words * 2);
     if (ok && pl->use_lane)
-        ok = pl->d_sorted16.ensure(tile_words * 2) && pl->d_meta.ensure(max_rank_span * 8);
+        ok = pl->d_meta.ensure(max_rank_span * 8);
     if (!ok) {
         zsc_hip_deflate_plan_destroy(pl);
         return Z_MEM_ERROR;
@@ -1293,7 +1294,7 @@ extern "C" ZlibReturn zsc_hip_deflate_plan_run(zsc_hip_deflate_plan *pl, const v
         const bool simple = pl->strategy == (uint32_t)Z_HUFFMAN_ONLY || pl->strategy == (uint32_t)Z_RLE;
         if (!simple) {
             hipLaunchKernelGGL(k_hash_sort, dim3(sb.ntiles), dim3(HS_WAVES * 64), 0, st, in, bufs,
-                               (const uint32_t *)sb.d_tile_owner.p, sorted, rank, dir,
+                               (const uint32_t *)sb.d_tile_owner.p, sorted, tmp_syms, rank, dir,
                                (uint16_t *)pl->d_sorted16.p, sb.ntiles);
             hipLaunchKernelGGL(k_link_prev, dim3(sb.ntiles), dim3(HS_WAVES * 64), 0, st, in, bufs,
                                (const uint32_t *)sb.d_tile_owner.p, (const uint16_t *)dir,
@@ -1326,7 +1327,7 @@ extern "C" ZlibReturn zsc_hip_deflate_plan_run(zsc_hip_deflate_plan *pl, const v
                 hipLaunchKernelGGL(kern, dim3(sb.cseg - sb.clane), dim3(SG_W * 64), 0, st, in, bufs,
                                    (const uint32_t *)sb.d_order.p, (const uint32_t *)sorted,
                                    (const uint16_t *)rank, (const uint16_t *)hib,
-                                   (const uint32_t *)cnt, tmp_syms, recs,
+                                   (const uint32_t *)cnt, (const uint16_t *)pl->d_sorted16.p, tmp_syms, recs,
                                    pout, (uint32_t *)pl->d_seg_tok.p, (uint16_t *)pl->d_seg_sidx.p,
                                    (const ZdSched *)pl->d_sched.p, cfg, sb.clane, sb.cseg - sb.clane);
             }
