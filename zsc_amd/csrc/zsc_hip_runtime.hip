@@ -1016,7 +1016,10 @@ static ZlibReturn plan_create(zsc_hip_deflate_plan **plan_out, U32 count, const 
     pl->strategy = (uint32_t)strategy;
     pl->bufs.resize(count);
 
-    uint64_t sub_limit = 8192ull << 20; /* input bytes per sub-batch (scratch is ~16 B per input byte) */
+    /* input bytes per sub-batch; the scratch is ~14 B per input byte OF ONE SUB-BATCH.  Measured on
+     * the x4096 batch (11.5 GB): 8 GiB sub-batches 3 641 MB/s with 165 GB of scratch, 4 GiB 3 631 MB/s
+     * with 83 GB, 2 GiB 3 552 MB/s with 41 GB (the tail of every sub-batch's parse is idle time) */
+    uint64_t sub_limit = 4096ull << 20;
     if (const char *e = getenv("ZSC_HIP_SUBBATCH_MB"))
         sub_limit = (uint64_t)atoll(e) << 20;
     if (sub_limit < (1ull << 20))
