@@ -43,16 +43,22 @@ struct InfCodeT {
     uint32_t empty;
 };
 
-/* per stream: 3.7 KiB, so that four streams per wave leave room for twelve waves on a CU */
+/* per stream: 2.2 KiB, so that four streams per wave (+ the CRC table) leave room for sixteen
+ * waves on a CU.  The code-length code is dead once the lengths are read, before the distance
+ * code is built, and shares its place; the CRC routine's exchange area lies in the stage, which
+ * is empty whenever a check value is computed (gzip header: nothing decoded yet; trailer: after
+ * the final flush). */
 typedef struct {
     InfCodeT<288> lit;
-    InfCodeT<32> dist;
-    InfCodeT<20> cl;
-    uint16_t lens[320];
-    uint8_t stage[INF_STAGE + 8];   /* output not yet stored: [flushed, pos), indexed modulo INF_STAGE */
-    uint32_t ckx[64];               /* exchange area of the CRC routine */
-    uint32_t (*cktab)[256];         /* its byte-loop table (1 KiB), shared by the streams of a wave */
+    union {
+        InfCodeT<32> dist;
+        InfCodeT<20> cl;
+    };
+    uint8_t lens[320];
+    __attribute__((aligned(16))) uint8_t stage[INF_STAGE + 8]; /* output not yet stored: [flushed, pos), indexed modulo INF_STAGE */
+    uint32_t (*cktab)[256];         /* the CRC byte-loop table (1 KiB), shared by the streams of a wave */
 } InfLds;
+#define INF_CKX(lds) ((uint32_t *)(lds)->stage) /* 64 words */
 
 /* where decoding goes on after an inflateSync: the stream is inflated again from there */
 typedef struct {
@@ -117,7 +123,7 @@ typedef struct {
 /* build a canonical decoder from code lengths.  kind 0: code-length code, 1: literal/
  * length, 2: distance.  Returns 0, or -1 for an invalid set (src/inftrees.c:168-177). */
 template <class CT>
-DEV int inf_build(CT *c, const uint16_t *lens, int n, int kind)
+DEV int inf_build(CT *c, const uint8_t *lens, int n, int kind)
 {
     int rc = 0;
     ON_GLANE0
@@ -566,7 +572,7 @@ DEV int inflate_stream(const InfJob &job, InfLds *lds, InfResult *res, InfResume
                 uint32_t got;
                 INF_NEED(16);
                 INF_TAKE(got, 16);
-                if ((wrap & 4) && got != (INF_CK(crc32_tx)<1>(src, upto, lds->cktab, lds->ckx) & 0xffffu))
+                if ((wrap & 4) && got != (INF_CK(crc32_tx)<1>(src, upto, lds->cktab, INF_CKX(lds)) & 0xffffu))
                     INF_BADX(16, 16); /* :944-950 */
             }
         } else {
@@ -644,7 +650,7 @@ DEV int inflate_stream(const InfJob &job, InfLds *lds, InfResult *res, InfResume
                 FOR_GLANES
                 {
                     for (int s = GLANE; s < 288; s += GRP)
-                        lds->lens[s] = (uint16_t)(s < 144 ? 8 : s < 256 ? 9 : s < 280 ? 7 : 8);
+                        lds->lens[s] = (uint8_t)(s < 144 ? 8 : s < 256 ? 9 : s < 280 ? 7 : 8);
                 }
                 WAVE_SYNC();
                 (void)inf_build(&lds->lit, lds->lens, 288, 1);
@@ -677,7 +683,7 @@ DEV int inflate_stream(const InfJob &job, InfLds *lds, InfResult *res, InfResume
                     INF_NEED(3);
                     INF_TAKE(v, 3);
                     const uint8_t order[19] = {16, 17, 18, 0, 8, 7, 9, 6, 10, 5, 11, 4, 12, 3, 13, 2, 14, 1, 15};
-                    ON_GLANE0 { lds->lens[order[i]] = (uint16_t)v; }
+                    ON_GLANE0 { lds->lens[order[i]] = (uint8_t)v; }
                     WAVE_SYNC();
                 }
                 if (inf_build(&lds->cl, lds->lens, 19, 0))
@@ -689,7 +695,7 @@ DEV int inflate_stream(const InfJob &job, InfLds *lds, InfResult *res, InfResume
                     if (sym < 0)
                         sym = 0; /* all-zero code-length code: CODELENS reads the marker's val 0, bits 1 (:1105-1114) */
                     if (sym < 16) {
-                        ON_GLANE0 { lds->lens[have] = (uint16_t)sym; }
+                        ON_GLANE0 { lds->lens[have] = (uint8_t)sym; }
                         WAVE_SYNC();
                         have++;
                         continue;
@@ -719,7 +725,7 @@ DEV int inflate_stream(const InfJob &job, InfLds *lds, InfResult *res, InfResume
                     FOR_GLANES
                     {
                         for (uint32_t k = (uint32_t)GLANE; k < rep; k += GRP)
-                            lds->lens[have + k] = (uint16_t)val;
+                            lds->lens[have + k] = (uint8_t)val;
                     }
                     WAVE_SYNC();
                     have += rep;
@@ -800,13 +806,19 @@ DEV int inflate_stream(const InfJob &job, InfLds *lds, InfResult *res, InfResume
                 uint32_t can = len;
                 if (can > cap - pos)
                     can = cap - pos;
-                /* lane-parallel copy: byte i comes from pos - dist + (i mod dist) */
+                /* lane-parallel copy: byte i comes from pos - dist + (i mod dist).  i <= 257, so the
+                 * quotient is floor((i + 0.5) / dist) in single precision -- (i + 0.5) / dist is never
+                 * within 1 / (2 dist) >= 2e-3 of an integer when dist <= i, and below 1 otherwise,
+                 * far more than the error of the reciprocal -- a handful of instructions where the
+                 * integer division is ~30 */
+                const float rdist = RCP_F32((float)dist);
                 for (uint32_t k = 0; k < can; k += GRP) {
                     FOR_GLANES
                     {
                         uint32_t i = k + (uint32_t)GLANE;
                         if (i < can) {
-                            uint32_t s = pos - dist + (i % dist);
+                            const uint32_t q = (uint32_t)(((float)i + 0.5f) * rdist);
+                            uint32_t s = pos - dist + (i - q * dist);
                             uint8_t b = s >= flushed ? lds->stage[s & (INF_STAGE - 1)] : dst[s];
                             lds->stage[(pos + i) & (INF_STAGE - 1)] = b;
                         }
@@ -843,7 +855,7 @@ DEV int inflate_stream(const InfJob &job, InfLds *lds, InfResult *res, InfResume
 #ifndef ZSC_WAVE_EMU
                 __threadfence_block();
 #endif
-                const uint32_t want = gzip ? INF_CK(crc32_tx)<1>(dst, pos, lds->cktab, lds->ckx) : INF_CK(adler32)(dst, pos);
+                const uint32_t want = gzip ? INF_CK(crc32_tx)<1>(dst, pos, lds->cktab, INF_CKX(lds)) : INF_CK(adler32)(dst, pos);
                 const uint32_t got = gzip ? v : ((v >> 24) | ((v >> 8) & 0xff00u) | ((v & 0xff00u) << 8) | (v << 24));
                 if (got != want)
                     INF_BADX(32, 32); /* :1333-1339 */

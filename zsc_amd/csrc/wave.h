@@ -124,6 +124,7 @@ static inline uint32_t emu_brev32(uint32_t v)
 }
 #define BREV32(x) emu_brev32(x)
 #define COPY16(dst, src) memcpy((dst), (src), 16)
+#define RCP_F32(x) (1.0f / (x))
 #define UNI(x) (x)
 
 #else
@@ -226,6 +227,7 @@ DEV uint32_t lds_u32(const uint8_t *base, uint32_t idx)
 #define UNI(x) ((uint32_t)__builtin_amdgcn_readfirstlane((int)(x)))
 /* both sides 16-byte aligned: one global_load_dwordx4 + one ds_write_b128 */
 #define COPY16(dst, src) (*(uint4 *)(dst) = *(const uint4 *)(src))
+#define RCP_F32(x) __builtin_amdgcn_rcpf(x) /* v_rcp_f32: 1 ulp */
 
 #endif
 
