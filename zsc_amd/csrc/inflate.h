@@ -30,7 +30,18 @@
 #include "checksum.h"
 #include "wave.h"
 
-#define INF_STAGE 1024u
+#ifndef INF_STAGE
+#define INF_STAGE 512u
+#endif
+#ifndef INF_WINDOW
+#define INF_WINDOW 1
+#endif
+/* output leaves the stage in pieces of INF_FLUSH_B bytes (a power of two); the stage must hold a
+ * piece less one byte, and the longest match or a 256-byte step of a stored block after it */
+#ifndef INF_FLUSH_B
+#define INF_FLUSH_B 128u
+#endif
+static_assert(INF_FLUSH_B - 1u + 258u <= INF_STAGE, "the stage holds the unflushed bytes and one match");
 
 template <int NSYM>
 struct InfCodeT {
@@ -43,8 +54,9 @@ struct InfCodeT {
     uint32_t empty;
 };
 
-/* per stream: 2.2 KiB, so that four streams per wave (+ the CRC table) leave room for sixteen
- * waves on a CU.  The code-length code is dead once the lengths are read, before the distance
+/* per stream: 1.7 KiB with a 512-byte stage, so that four streams per wave (+ the CRC table)
+ * leave room for twenty waves on a CU (measured on BASELINE config 4: 12 waves 30.4 GB/s, 16 waves
+ * 40.9, 20 waves 43.2 -- by then the vector ALUs are the limit).  The code-length code is dead once the lengths are read, before the distance
  * code is built, and shares its place; the CRC routine's exchange area lies in the stage, which
  * is empty whenever a check value is computed (gzip header: nothing decoded yet; trailer: after
  * the final flush). */
@@ -375,12 +387,16 @@ DEV int inflate_stream(const InfJob &job, InfLds *lds, InfResult *res, InfResume
 /* store the completed 256-byte pieces of the staging area */
 #define INF_FLUSH(all)                                                                         \
     do {                                                                                       \
-        uint32_t _upto = (all) ? pos : (pos & ~255u);                                          \
+        uint32_t _upto = (all) ? pos : (pos & ~(INF_FLUSH_B - 1u));                                          \
         while (flushed < _upto) {                                                              \
-            uint32_t _len = _upto - flushed < 256u ? _upto - flushed : 256u;                   \
+            /* up to the next multiple of INF_FLUSH_B: after an inflateSync `flushed` starts at  \
+             * any byte, and a dword read must not straddle the end of the ring */              \
+            uint32_t _len = INF_FLUSH_B - (flushed & (INF_FLUSH_B - 1u));                       \
+            if (_len > _upto - flushed)                                                        \
+                _len = _upto - flushed;                                                        \
             FOR_GLANES                                                                         \
             {                                                                                  \
-                /* (flushed is a multiple of 256 and dst 16-byte aligned: whole dwords, then the \
+                /* (past the first piece flushed is a multiple of INF_FLUSH_B, and dst is 16-byte aligned: whole dwords, then the \
                  * last bytes of the stream) */                                                \
                 for (uint32_t _k = 4u * (uint32_t)GLANE; _k + 4u <= _len; _k += 4u * GRP) {    \
                     uint32_t _w;                                                               \
@@ -774,7 +790,7 @@ DEV int inflate_stream(const InfJob &job, InfLds *lds, InfResult *res, InfResume
                     ON_GLANE0 { lds->stage[pos & (INF_STAGE - 1)] = (uint8_t)sym; }
                     WAVE_SYNC();
                     pos++;
-                    if ((pos & 255u) == 0)
+                    if ((pos & (INF_FLUSH_B - 1u)) == 0)
                         INF_FLUSH(0);
                     continue;
                 }
@@ -819,7 +835,10 @@ DEV int inflate_stream(const InfJob &job, InfLds *lds, InfResult *res, InfResume
                         if (i < can) {
                             const uint32_t q = (uint32_t)(((float)i + 0.5f) * rdist);
                             uint32_t s = pos - dist + (i - q * dist);
-                            uint8_t b = s >= flushed ? lds->stage[s & (INF_STAGE - 1)] : dst[s];
+                            /* the ring still holds what was flushed until it is written over: every
+                             * byte less than INF_STAGE before the end of this copy comes from LDS, only
+                             * older ones are read back from the output in global memory */
+                            uint8_t b = (INF_WINDOW ? s + INF_STAGE >= pos + can : s >= flushed) ? lds->stage[s & (INF_STAGE - 1)] : dst[s];
                             lds->stage[(pos + i) & (INF_STAGE - 1)] = b;
                         }
                     }
@@ -828,7 +847,7 @@ DEV int inflate_stream(const InfJob &job, InfLds *lds, InfResult *res, InfResume
                 {
                     const uint32_t before = pos;
                     pos += can;
-                    if ((before >> 8) != (pos >> 8))
+                    if ((before / INF_FLUSH_B) != (pos / INF_FLUSH_B))
                         INF_FLUSH(0);
                 }
                 if (can < len) {

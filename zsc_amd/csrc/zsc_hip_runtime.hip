@@ -608,7 +608,10 @@ typedef struct {
 
 /* kernel 5: one group of INF_GROUP lanes per compressed stream, 64 / INF_GROUP streams per wavefront */
 #define INF_PER_WAVE (64 / INF_GROUP)
-__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 4))) void k_inflate(const uint8_t *__restrict__ src,
+#ifndef INF_WAVES_EU
+#define INF_WAVES_EU 5 /* 96 VGPRs, with 8 KiB of LDS per wave (512-byte stages): 20 waves per CU */
+#endif
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(INF_WAVES_EU, INF_WAVES_EU))) void k_inflate(const uint8_t *__restrict__ src,
                                                 uint8_t *__restrict__ dst,
                                                 const ZdInfItem *__restrict__ items,
                                                 const uint32_t *__restrict__ order,
