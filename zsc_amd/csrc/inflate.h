@@ -100,8 +100,10 @@ typedef struct {
     uint32_t bits;     /* valid bits in hold */
     uint32_t next;     /* next input byte to pull into hold */
     uint32_t chunk_at; /* input offset of the chunk held in `cur` (multiple of 256) */
-    uint64_t used;     /* bits consumed so far */
 } InfBits;
+
+/* bits consumed so far: every byte pulled into hold, less what is still there */
+#define BR_USED ((uint64_t)br.next * 8u - br.bits)
 
 #define INF_OK 0
 #define INF_END 1
@@ -259,7 +261,6 @@ DEV int inflate_stream(const InfJob &job, InfLds *lds, InfResult *res, InfResume
     br.bits = 0;
     br.next = 0;
     br.chunk_at = 0;
-    br.used = 0;
     LANEVAR(uint32_t, cur); /* dword GLANE of the current 256-byte input chunk */
     FOR_GLANES
     {
@@ -307,6 +308,12 @@ DEV int inflate_stream(const InfJob &job, InfLds *lds, InfResult *res, InfResume
             }                                                                                 \
             const uint32_t _o = br.next - br.chunk_at;                                        \
             const uint32_t _w = GREADLANE(cur, _o >> 2);                                       \
+            if ((_o & 3u) == 0 && n - br.next >= 4u) { /* (br.bits <= 32) the whole dword */    \
+                br.hold |= (uint64_t)_w << br.bits;                                           \
+                br.bits += 32u;                                                               \
+                br.next += 4u;                                                                \
+                continue;                                                                     \
+            }                                                                                 \
             /* take the bytes of this dword from the current one on (up to 4) */              \
             uint32_t _take = 4u - (_o & 3u);                                                  \
             if (_take > n - br.next)                                                          \
@@ -344,7 +351,6 @@ DEV int inflate_stream(const InfJob &job, InfLds *lds, InfResult *res, InfResume
         (var) = (uint32_t)(br.hold & ((1ull << _nb) - 1ull));      \
         br.hold >>= _nb;                                           \
         br.bits -= _nb;                                            \
-        br.used += _nb;                                            \
     } while (0)
 
 /* A data error.  inflateSync starts its search in the bits the reference has buffered at
@@ -353,17 +359,16 @@ DEV int inflate_stream(const InfJob &job, InfLds *lds, InfResult *res, InfResume
  * usual case is "whatever is left of the current byte". */
 #define INF_BADX(BACK, RB)                                  \
     do {                                                    \
-        sy_start = br.used - (uint64_t)(int64_t)(BACK);     \
+        sy_start = BR_USED - (uint64_t)(int64_t)(BACK);     \
         sy_rb = (uint32_t)(RB);                             \
         fail_line = __LINE__;                               \
         goto bad;                                           \
     } while (0)
-#define INF_BAD INF_BADX(0, (8u - (uint32_t)(br.used & 7u)) & 7u)
+#define INF_BAD INF_BADX(0, (8u - (uint32_t)(BR_USED & 7u)) & 7u)
 
 /* put the bit reader at byte P of the input */
 #define INF_SEEK(P)                                                                           \
     do {                                                                                      \
-        br.used = (uint64_t)(P)*8u;                                                           \
         br.hold = 0;                                                                          \
         br.bits = 0;                                                                          \
         br.next = (P);                                                                        \
@@ -462,7 +467,6 @@ DEV int inflate_stream(const InfJob &job, InfLds *lds, InfResult *res, InfResume
         (OUTSYM) = (int)(C)->sym[(C)->offs[_len] + (_code - (C)->first[_len])];                  \
         br.hold >>= _len;                                                                     \
         br.bits -= _len;                                                                      \
-        br.used += _len;                                                                      \
     } while (0)
 
 /* The same for the two codes of the symbol loop, with each length's first code, count and
@@ -516,7 +520,6 @@ DEV int inflate_stream(const InfJob &job, InfLds *lds, InfResult *res, InfResume
         (OUTSYM) = (int)GUNI((C)->sym[_ol + (_code - (_fl & 0xffffu))]);                      \
         br.hold >>= _len;                                                                     \
         br.bits -= _len;                                                                      \
-        br.used += _len;                                                                      \
     } while (0)
 
     /* HEAD .. HCRC, reference src/inflate.c:740-954 */
@@ -584,7 +587,7 @@ DEV int inflate_stream(const InfJob &job, InfLds *lds, InfResult *res, InfResume
                 } while (t != 0);
             }
             if (flags & 0x0200) {
-                const uint32_t upto = (uint32_t)(br.used >> 3);
+                const uint32_t upto = (uint32_t)(BR_USED >> 3);
                 uint32_t got;
                 INF_NEED(16);
                 INF_TAKE(got, 16);
@@ -609,7 +612,6 @@ DEV int inflate_stream(const InfJob &job, InfLds *lds, InfResult *res, InfResume
                  * without its exit bookkeeping, so nothing counts as consumed */
                 INF_NEED(32);
                 rc = INF_NEED_DICT;
-                br.used = 0;
                 goto done;
             }
         }
@@ -633,7 +635,7 @@ DEV int inflate_stream(const InfJob &job, InfLds *lds, InfResult *res, InfResume
                 INF_BADX(32, 32); /* LEN/NLEN still in hold, :1011-1016 */
             uint32_t len = v & 0xffff;
             /* the remaining bytes of the bit buffer belong to the stored data */
-            const uint32_t at = (uint32_t)(br.used >> 3); /* input offset of the first data byte */
+            const uint32_t at = (uint32_t)(BR_USED >> 3); /* input offset of the first data byte */
             uint32_t can = len;
             int short_in = 0, short_out = 0;
             if (can > n - at) {
@@ -721,7 +723,7 @@ DEV int inflate_stream(const InfJob &job, InfLds *lds, InfResult *res, InfResume
                         INF_NEED(2);
                         if (have == 0) {
                             /* NEEDBITS(here.bits + 2) may have pulled one byte more (:1116-1123) */
-                            const uint32_t padb = (8u - (uint32_t)(br.used & 7u)) & 7u;
+                            const uint32_t padb = (8u - (uint32_t)(BR_USED & 7u)) & 7u;
                             INF_BADX(0, padb >= 2u ? padb : padb + 8u);
                         }
                         val = lds->lens[have - 1];
@@ -777,6 +779,11 @@ DEV int inflate_stream(const InfJob &job, InfLds *lds, InfResult *res, InfResume
             }
             const uint32_t lmax = GUNI(lds->lit.max_len), lempty = GUNI(lds->lit.empty);
             const uint32_t dmaxlen = GUNI(lds->dist.max_len), dempty = GUNI(lds->dist.empty);
+            /* (Two restructurings of this loop were measured on BASELINE config 4 and dropped: literal
+             * runs as an inner loop of their own, 780 ms against 720 ms; and an inflate_fast-style
+             * copy of the loop without the input / output exhaustion tests, entered while 8 input
+             * bytes and 258 output bytes remain, 867 ms against 712 ms -- the second copy of the
+             * decoder costs more registers and instruction cache than the dropped tests save.) */
             for (;;) {
                 int sym;
                 INF_DECODE_R(&lds->lit, lfc, lof, lfc2, lof2, lmax, lempty, sym);
@@ -911,7 +918,7 @@ done:
     INF_FLUSH(1);
     ON_GLANE0
     {
-        uint32_t used_bytes = (uint32_t)((br.used + 7u) >> 3);
+        uint32_t used_bytes = (uint32_t)((BR_USED + 7u) >> 3);
         if (exhausted || used_bytes > n)
             used_bytes = n;
         res->status = rc == INF_END ? 0 : rc;
