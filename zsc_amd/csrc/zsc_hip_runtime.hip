@@ -803,8 +803,10 @@ struct DevBuf {
         if (p)
             return true;
         if (hipMalloc(&p, need) != hipSuccess) {
+            (void)hipGetLastError(); /* (the error is sticky: it must not be charged to the next launch) */
             g_dev_cache.trim(); /* what is kept may be what is missing */
             if (hipMalloc(&p, need) != hipSuccess) {
+                (void)hipGetLastError();
                 p = nullptr;
                 ZSC_WARN1("zsc_hip: hipMalloc of %zu bytes failed.", need);
                 return false;
@@ -1258,6 +1260,7 @@ extern "C" ZlibReturn zsc_hip_deflate_plan_run(zsc_hip_deflate_plan *pl, const v
     ZSC_ASSERT(d_output != Z_NULL);
     hipStream_t st = (hipStream_t)hip_stream;
     pl->last_stream = st;
+    (void)hipGetLastError(); /* an error some earlier call on this thread left behind is not this run's */
     const uint8_t *in = (const uint8_t *)d_input;
     uint8_t *out = (uint8_t *)d_output;
     ZdLevel cfg = kLevels[pl->level];
@@ -2331,6 +2334,7 @@ extern "C" ZlibReturn zsc_hip_inflate_plan_run(zsc_hip_inflate_plan *pl, const v
     pl->last_stream = st;
     if (pl->count == 0)
         return Z_OK;
+    (void)hipGetLastError(); /* (see zsc_hip_deflate_plan_run) */
     pl->last_src = d_src;
     pl->last_dst = d_dst;
     HIP_TRY(hipMemsetAsync(pl->d_resume.p, 0, sizeof(InfResume) * pl->count, st), return Z_STREAM_ERROR);
