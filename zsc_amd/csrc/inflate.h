@@ -36,6 +36,9 @@
 #ifndef INF_WINDOW
 #define INF_WINDOW 1
 #endif
+#ifndef INF_LIT_LOOP
+#define INF_LIT_LOOP 1
+#endif
 /* output leaves the stage in pieces of INF_FLUSH_B bytes (a power of two); the stage must hold a
  * piece less one byte, and the longest match or a 256-byte step of a stored block after it */
 #ifndef INF_FLUSH_B
@@ -786,6 +789,24 @@ DEV int inflate_stream(const InfJob &job, InfLds *lds, InfResult *res, InfResume
              * decoder costs more registers and instruction cache than the dropped tests save.) */
             for (;;) {
                 int sym;
+#if INF_LIT_LOOP
+                for (;;) {
+                    INF_DECODE_R(&lds->lit, lfc, lof, lfc2, lof2, lmax, lempty, sym);
+                    if ((uint32_t)sym >= 256u) /* a length, the end of the block, or -2 */
+                        break;
+                    if (pos >= cap) {
+                        rc = INF_BUF;
+                        goto done;
+                    }
+                    ON_GLANE0 { lds->stage[pos & (INF_STAGE - 1)] = (uint8_t)sym; }
+                    WAVE_SYNC();
+                    pos++;
+                    if ((pos & (INF_FLUSH_B - 1u)) == 0)
+                        INF_FLUSH(0);
+                }
+                if (sym == -2)
+                    INF_BAD;
+#else
                 INF_DECODE_R(&lds->lit, lfc, lof, lfc2, lof2, lmax, lempty, sym);
                 if (sym == -2)
                     INF_BAD;
@@ -801,6 +822,7 @@ DEV int inflate_stream(const InfJob &job, InfLds *lds, InfResult *res, InfResume
                         INF_FLUSH(0);
                     continue;
                 }
+#endif
                 if (sym == 256)
                     break;
                 if (sym > 285)

@@ -626,22 +626,31 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(INF_WAVES_EU
     InfLds *lds = &lds_all[grp];
     if ((threadIdx.x & (INF_GROUP - 1u)) == 0)
         lds->cktab = crc_table;
-    const uint32_t slot = blockIdx.x * INF_PER_WAVE + grp;
-    if (slot >= count)
-        return;
-    const uint32_t i = order[slot];
-    if (resume[i].state == 2u)
-        return; /* finished in an earlier launch (only streams that resynchronise come back) */
-    const ZdInfItem it = items[i];
-    InfJob job;
-    job.src = src + it.src_off;
-    job.n = it.src_len;
-    job.dst = dst + it.dst_off;
-    job.cap = it.dst_cap;
-    job.window_bits = window_bits;
-    if (inflate_stream(job, lds, &res[i], &resume[i])) {
+    /* every group takes streams from one queue (pending[1], longest output first) until it is
+     * empty: streams of one length still differ a lot in decoding time (a table-like member has
+     * a third of a text member's symbols), and with a fixed four streams per wavefront the
+     * groups that finish early idle until the slowest one is done */
+    for (;;) {
+        uint32_t slot = 0;
         if ((threadIdx.x & (INF_GROUP - 1u)) == 0)
-            atomicAdd(pending, 1u); /* the host launches once more for these */
+            slot = atomicAdd(pending + 1, 1u);
+        slot = (uint32_t)__shfl((int)slot, (int)(threadIdx.x & (64u - INF_GROUP)));
+        if (slot >= count)
+            break;
+        const uint32_t i = order[slot];
+        if (resume[i].state == 2u)
+            continue; /* finished in an earlier launch (only streams that resynchronise come back) */
+        const ZdInfItem it = items[i];
+        InfJob job;
+        job.src = src + it.src_off;
+        job.n = it.src_len;
+        job.dst = dst + it.dst_off;
+        job.cap = it.dst_cap;
+        job.window_bits = window_bits;
+        if (inflate_stream(job, lds, &res[i], &resume[i])) {
+            if ((threadIdx.x & (INF_GROUP - 1u)) == 0)
+                atomicAdd(pending, 1u); /* the host launches once more for these */
+        }
     }
 }
 
@@ -659,6 +668,7 @@ const ZdLevel kLevels[10] = {
 std::once_flag g_init_once;
 int g_init_status = Z_STREAM_ERROR;
 int g_device = -1; /* the device this process's plans, scratch and kernels live on */
+int g_cus = 256;    /* its compute units */
 char g_device_info[256] = "uninitialised";
 
 #define HIP_TRY(expr, fail)                                                              \
@@ -700,6 +710,7 @@ void do_init(int ordinal)
         g_init_status = Z_STREAM_ERROR;
         return;
     }
+    g_cus = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
     snprintf(g_device_info, sizeof g_device_info, "%s | %s | %d CUs | %.1f GiB", prop.name,
              prop.gcnArchName, prop.multiProcessorCount,
              (double)prop.totalGlobalMem / (1024.0 * 1024.0 * 1024.0));
@@ -2264,6 +2275,14 @@ extern "C" ZlibReturn zsc_hip_compress_batch(U32 count, const U8 *const *sources
     return rc;
 }
 
+/* wavefronts of k_inflate: enough to fill every CU at its occupancy, never more than the streams need */
+static uint32_t inflate_grid(uint32_t count)
+{
+    const uint32_t need = (count + INF_PER_WAVE - 1) / INF_PER_WAVE;
+    const uint32_t fill = (uint32_t)g_cus * 4u * INF_WAVES_EU;
+    return std::max(1u, std::min(need, fill));
+}
+
 struct zsc_hip_inflate_plan {
     uint32_t count = 0;
     int32_t window_bits = 15;
@@ -2300,10 +2319,25 @@ extern "C" ZlibReturn zsc_hip_inflate_plan_create(zsc_hip_inflate_plan **plan_ou
     }
     std::stable_sort(order.begin(), order.end(),
                      [&](uint32_t a, uint32_t b) { return items[a].dst_cap > items[b].dst_cap; });
+    if (const char *e = getenv("ZSC_HIP_INFLATE_SPREAD")) {
+        /* measurement aid: a benchmark batch of D distinct streams replicated R times puts the R
+         * copies of a stream next to each other in the length order, so the streams that share a
+         * wavefront are identical and never diverge.  With D given, neighbours in the order are
+         * DIFFERENT streams of nearly the same length -- what a batch of all-different streams
+         * looks like. */
+        const uint32_t d = (uint32_t)atoi(e);
+        if (d > 1 && count % d == 0) {
+            const uint32_t r = count / d;
+            std::vector<uint32_t> spread(count);
+            for (uint32_t s2 = 0; s2 < count; s2++)
+                spread[s2] = order[(s2 % d) * r + s2 / d];
+            order.swap(spread);
+        }
+    }
     bool ok = pl->d_items.ensure(sizeof(ZdInfItem) * std::max(1u, count)) &&
               pl->d_order.ensure(4ull * std::max(1u, count)) &&
               pl->d_res.ensure(sizeof(InfResult) * std::max(1u, count)) &&
-              pl->d_resume.ensure(sizeof(InfResume) * std::max(1u, count)) && pl->d_pending.ensure(4);
+              pl->d_resume.ensure(sizeof(InfResume) * std::max(1u, count)) && pl->d_pending.ensure(8);
     if (ok && count) {
         ok = hipMemcpy(pl->d_items.p, items.data(), sizeof(ZdInfItem) * count,
                        hipMemcpyHostToDevice) == hipSuccess &&
@@ -2338,9 +2372,9 @@ extern "C" ZlibReturn zsc_hip_inflate_plan_run(zsc_hip_inflate_plan *pl, const v
     pl->last_src = d_src;
     pl->last_dst = d_dst;
     HIP_TRY(hipMemsetAsync(pl->d_resume.p, 0, sizeof(InfResume) * pl->count, st), return Z_STREAM_ERROR);
-    HIP_TRY(hipMemsetAsync(pl->d_pending.p, 0, 4, st), return Z_STREAM_ERROR);
+    HIP_TRY(hipMemsetAsync(pl->d_pending.p, 0, 8, st), return Z_STREAM_ERROR); /* [0] streams to relaunch, [1] the queue */
     (void)hipEventRecord(pl->ev0, st);
-    hipLaunchKernelGGL(k_inflate, dim3((pl->count + INF_PER_WAVE - 1) / INF_PER_WAVE), dim3(64), 0, st, (const uint8_t *)d_src,
+    hipLaunchKernelGGL(k_inflate, dim3(inflate_grid(pl->count)), dim3(64), 0, st, (const uint8_t *)d_src,
                        (uint8_t *)d_dst, (const ZdInfItem *)pl->d_items.p,
                        (const uint32_t *)pl->d_order.p, (InfResult *)pl->d_res.p,
                        (InfResume *)pl->d_resume.p, (uint32_t *)pl->d_pending.p, pl->window_bits,
@@ -2365,8 +2399,8 @@ extern "C" ZlibReturn zsc_hip_inflate_plan_results(zsc_hip_inflate_plan *pl, U32
         HIP_TRY(hipMemcpy(&pending, pl->d_pending.p, 4, hipMemcpyDeviceToHost), return Z_STREAM_ERROR);
         if (pending == 0 || round > (1u << 30))
             break;
-        HIP_TRY(hipMemsetAsync(pl->d_pending.p, 0, 4, pl->last_stream), return Z_STREAM_ERROR);
-        hipLaunchKernelGGL(k_inflate, dim3((pl->count + INF_PER_WAVE - 1) / INF_PER_WAVE), dim3(64), 0, pl->last_stream,
+        HIP_TRY(hipMemsetAsync(pl->d_pending.p, 0, 8, pl->last_stream), return Z_STREAM_ERROR);
+        hipLaunchKernelGGL(k_inflate, dim3(inflate_grid(pl->count)), dim3(64), 0, pl->last_stream,
                            (const uint8_t *)pl->last_src, (uint8_t *)pl->last_dst,
                            (const ZdInfItem *)pl->d_items.p, (const uint32_t *)pl->d_order.p,
                            (InfResult *)pl->d_res.p, (InfResume *)pl->d_resume.p,
