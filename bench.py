@@ -118,7 +118,7 @@ def cpu_inflate_baseline(streams, outs, seconds_budget: float = 10.0):
                       f"zsc_uncompress_gzip semantics, one codec instance per thread, {dt:.1f} s wall"}
 
 
-def bench_inflate(dev, stream, nstreams: int, distinct: int, fence):
+def bench_inflate(dev, stream, nstreams: int, distinct: int, fence, orders=("neighbours_differ", "neighbours_identical")):
     """BASELINE config 4: inflate-only over gzip members of 4-64 KiB."""
     import torch
     import zsc_amd
@@ -149,7 +149,7 @@ def bench_inflate(dev, stream, nstreams: int, distinct: int, fence):
     # makes neighbours in that order DIFFERENT members of nearly the same length -- what a batch of
     # all-different streams looks like -- and that is the figure reported as `value`.
     results = {}
-    for mode in ("neighbours_differ", "neighbours_identical"):
+    for mode in orders:
         if mode == "neighbours_differ" and nstreams % distinct == 0 and nstreams > distinct:
             os.environ["ZSC_HIP_INFLATE_SPREAD"] = str(distinct)
         else:
@@ -195,8 +195,8 @@ def bench_inflate(dev, stream, nstreams: int, distinct: int, fence):
         results[mode] = (wall, kms, bool(ok))
         ip.close()
         del d_src, d_dst, rows, d_mask, first
-    wall, kms, ok = results["neighbours_differ"]
-    wall2, kms2, ok2 = results["neighbours_identical"]
+    wall, kms, ok = results[orders[0]]
+    wall2, kms2, ok2 = results[orders[-1]]
     ok = ok and ok2
     out_bytes, in_bytes = sum(all_caps), sum(all_slens)
     achieved = (out_bytes + in_bytes) / (kms * 1e-3) / 1e9 if kms > 0 else 0.0
@@ -208,6 +208,7 @@ def bench_inflate(dev, stream, nstreams: int, distinct: int, fence):
                          "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 6),
                          "kernel_ms": round(kms, 3), "algorithmic_bytes_per_launch": out_bytes + in_bytes,
                          "traffic": None},
+            "order": orders[0],
             "identical_neighbours": {"value": round(out_bytes / wall2 / 1e6, 2), "kernel_ms": round(kms2, 3),
                                      "note": "the same batch in plain length order: the replicas of a member share "
                                              "wavefronts and never diverge -- an artefact of replication, not a "
@@ -282,6 +283,8 @@ def main() -> None:
     ap.add_argument("--inflate-streams", type=int, default=1048576,
                     help="gzip members of the inflate section (BASELINE config 4; 0: skip)")
     ap.add_argument("--inflate-distinct", type=int, default=2048, help="distinct gzip members among them")
+    ap.add_argument("--inflate-order", choices=("both", "differ", "identical"), default="both",
+                    help="which decode order(s) of the replicated batch to measure (profiling aid)")
     ap.add_argument("--stage-on-root", action="store_true",
                     help="N > 1 only: the whole job's input is staged in GPU 0's memory and scattered to the "
                          "ranks point to point, the streams are gathered back (BASELINE config 5's wording; "
@@ -553,7 +556,11 @@ def main() -> None:
         # the rest of BASELINE's metric, beside the headline (one GPU only: these are not sharded)
         torch.cuda.empty_cache()
         if args.inflate_streams > 0:
-            info, members, outs = bench_inflate(dev, stream, args.inflate_streams, args.inflate_distinct, fence)
+            orders = {"both": ("neighbours_differ", "neighbours_identical"), "differ": ("neighbours_differ",),
+                      "identical": ("neighbours_identical",)}[args.inflate_order]
+            info, members, outs = bench_inflate(dev, stream, args.inflate_streams, args.inflate_distinct, fence, orders)
+            if len(orders) == 1:
+                info.pop("identical_neighbours")
             if not args.no_cpu_baseline:
                 info["cpu_baseline"] = cpu_inflate_baseline(members, outs)
             line["inflate"] = info
