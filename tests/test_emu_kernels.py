@@ -13,9 +13,9 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 
 # the kernel sources at two wave widths: 64 lanes, and 16 lanes -- the width group code (wave_group.h:
 # the inflate decoder, optionally the segmented parser) has on the GPU, where four groups share a wave
-# (group16-stage1024: the inflate decoder with a 1024-byte stage flushed in 256-byte pieces instead of
-# 512 / 128 -- going from one to the other is how a flush that straddled the ring's end after an
-# inflateSync was found; only the inflate test runs on it)
+# (group16-stage1024: the inflate decoder with a 1024-byte output ring instead of 512 bytes -- building
+# it for a second size is how a read that straddled the ring's end after an inflateSync was found in
+# round 2; only the inflate test runs on it)
 @pytest.fixture(scope="module", params=["libzsc_emu.so", "libzsc_emu16.so", "libzsc_emu8.so", "libzsc_emu16s.so"],
                 ids=["wave64", "group16", "group8", "group16-stage1024"])
 def emu(request):

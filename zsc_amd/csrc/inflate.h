@@ -33,18 +33,10 @@
 #ifndef INF_STAGE
 #define INF_STAGE 512u
 #endif
-#ifndef INF_WINDOW
-#define INF_WINDOW 1
-#endif
 #ifndef INF_LIT_LOOP
 #define INF_LIT_LOOP 1
 #endif
-/* output leaves the stage in pieces of INF_FLUSH_B bytes (a power of two); the stage must hold a
- * piece less one byte, and the longest match or a 256-byte step of a stored block after it */
-#ifndef INF_FLUSH_B
-#define INF_FLUSH_B 128u
-#endif
-static_assert(INF_FLUSH_B - 1u + 258u <= INF_STAGE, "the stage holds the unflushed bytes and one match");
+static_assert(INF_STAGE >= 512u && (INF_STAGE & (INF_STAGE - 1u)) == 0, "the ring is a power of two and holds the longest match");
 
 template <int NSYM>
 struct InfCodeT {
@@ -70,7 +62,7 @@ typedef struct {
         InfCodeT<20> cl;
     };
     uint8_t lens[320];
-    __attribute__((aligned(16))) uint8_t stage[INF_STAGE + 8]; /* output not yet stored: [flushed, pos), indexed modulo INF_STAGE */
+    __attribute__((aligned(16))) uint8_t stage[INF_STAGE + 8]; /* the last INF_STAGE bytes of output, indexed modulo INF_STAGE: the source of near matches */
     uint32_t (*cktab)[256];         /* the CRC byte-loop table (1 KiB), shared by the streams of a wave */
 } InfLds;
 #define INF_CKX(lds) ((uint32_t *)(lds)->stage) /* 64 words */
@@ -279,7 +271,7 @@ DEV int inflate_stream(const InfJob &job, InfLds *lds, InfResult *res, InfResume
     }
 
     const int resumed = GUNI(rs->state) == 1u;
-    uint32_t pos = 0, flushed = 0; /* output bytes produced / stored to dst */
+    uint32_t pos = 0; /* output bytes produced (each is stored to dst as it is made) */
     uint32_t dmax = 32768u;
     int gzip = 0;
     int rc = INF_OK;
@@ -334,17 +326,30 @@ DEV int inflate_stream(const InfJob &job, InfLds *lds, InfResult *res, InfResume
         }                                                                                     \
     } while (0)
 
+/* what happens when the input runs out / the output is full: by default straight to the exit
+ * bookkeeping; the symbol loop redefines both (and INF_BAD) to leave through ONE exit with an
+ * event code, so that the loop keeps a simple shape (the compiler otherwise threads a dispatch
+ * variable and copies of the live state through every join of the loop) */
+#define INF_ON_EXHAUST   \
+    do {                 \
+        exhausted = 1;   \
+        rc = INF_BUF;    \
+        goto done;       \
+    } while (0)
+#define INF_ON_FULL      \
+    do {                 \
+        rc = INF_BUF;    \
+        goto done;       \
+    } while (0)
+
 /* need nb (<= 32) bits; on failure the input is exhausted */
 #define INF_NEED(nb)                     \
     do {                                 \
         const uint32_t _need = (uint32_t)(nb); \
         if (br.bits < _need) {           \
             INF_REFILL();                \
-            if (br.bits < _need) {       \
-                exhausted = 1;           \
-                rc = INF_BUF;            \
-                goto done;               \
-            }                            \
+            if (br.bits < _need)         \
+                INF_ON_EXHAUST;          \
         }                                \
     } while (0)
 
@@ -392,31 +397,6 @@ DEV int inflate_stream(const InfJob &job, InfLds *lds, InfResult *res, InfResume
         }                                                                                     \
     } while (0)
 
-/* store the completed 256-byte pieces of the staging area */
-#define INF_FLUSH(all)                                                                         \
-    do {                                                                                       \
-        uint32_t _upto = (all) ? pos : (pos & ~(INF_FLUSH_B - 1u));                                          \
-        while (flushed < _upto) {                                                              \
-            /* up to the next multiple of INF_FLUSH_B: after an inflateSync `flushed` starts at  \
-             * any byte, and a dword read must not straddle the end of the ring */              \
-            uint32_t _len = INF_FLUSH_B - (flushed & (INF_FLUSH_B - 1u));                       \
-            if (_len > _upto - flushed)                                                        \
-                _len = _upto - flushed;                                                        \
-            FOR_GLANES                                                                         \
-            {                                                                                  \
-                /* (past the first piece flushed is a multiple of INF_FLUSH_B, and dst is 16-byte aligned: whole dwords, then the \
-                 * last bytes of the stream) */                                                \
-                for (uint32_t _k = 4u * (uint32_t)GLANE; _k + 4u <= _len; _k += 4u * GRP) {    \
-                    uint32_t _w;                                                               \
-                    __builtin_memcpy(&_w, &lds->stage[(flushed + _k) & (INF_STAGE - 1)], 4);   \
-                    __builtin_memcpy(dst + flushed + _k, &_w, 4);                              \
-                }                                                                              \
-                for (uint32_t _k = (_len & ~3u) + (uint32_t)GLANE; _k < _len; _k += GRP)       \
-                    dst[flushed + _k] = lds->stage[(flushed + _k) & (INF_STAGE - 1)];          \
-            }                                                                                  \
-            flushed += _len;                                                                   \
-        }                                                                                      \
-    } while (0)
 
 /* decode one symbol of code C into `sym`: -2 when the bits are not a code of the set */
 #define INF_DECODE(C, OUTSYM)                                                                    \
@@ -461,11 +441,8 @@ DEV int inflate_stream(const InfJob &job, InfLds *lds, InfResult *res, InfResume
             break;                                                                            \
         }                                                                                     \
         const uint32_t _len = (uint32_t)CTZ64(_m);                                            \
-        if (br.bits < _len) {                                                                 \
-            exhausted = 1;                                                                    \
-            rc = INF_BUF;                                                                     \
-            goto done;                                                                        \
-        }                                                                                     \
+        if (br.bits < _len)                                                                   \
+            INF_ON_EXHAUST;                                                                   \
         const uint32_t _code = _r >> (15 - _len);                                             \
         (OUTSYM) = (int)(C)->sym[(C)->offs[_len] + (_code - (C)->first[_len])];                  \
         br.hold >>= _len;                                                                     \
@@ -475,18 +452,10 @@ DEV int inflate_stream(const InfJob &job, InfLds *lds, InfResult *res, InfResume
 /* The same for the two codes of the symbol loop, with each length's first code, count and
  * symbol offset held by lane `length` in registers (FC = first | count << 16, OF = offs):
  * one LDS read per symbol instead of five. */
-#define INF_DECODE_R(C, FC, OF, FC2, OF2, MAXLEN, EMPTY, OUTSYM)                               \
+#define INF_DECODE_R(C, FC, OF, FC2, OF2, MAXLEN, WHICH, OUTSYM)                               \
     do {                                                                                      \
         if (br.bits < 15)                                                                     \
             INF_REFILL();                                                                     \
-        if (EMPTY) {                                                                          \
-            INF_NEED(1);                                                                      \
-            uint32_t _d1;                                                                     \
-            INF_TAKE(_d1, 1);                                                                 \
-            (void)_d1;                                                                        \
-            (OUTSYM) = -2;                                                                    \
-            break;                                                                            \
-        }                                                                                     \
         const uint32_t _peek = (uint32_t)br.hold & 0x7fffu;                                   \
         const uint32_t _r = BREV32(_peek) >> 17; /* the 15 bits MSB first */                  \
         LANEVAR(int, _hit);                                                                   \
@@ -503,20 +472,11 @@ DEV int inflate_stream(const InfJob &job, InfLds *lds, InfResult *res, InfResume
                         (uint32_t)(_c2 - (LV(FC2) & 0xffffu)) < (LV(FC2) >> 16);              \
         }                                                                                     \
         const uint64_t _m = GBALLOT(_hit) | (INF_SLOTS > 1 ? GBALLOT(_hit2) << (GRP & 63u) : 0ull); \
-        if (_m == 0) {                                                                        \
-            INF_NEED(MAXLEN);                                                                 \
-            uint32_t _d;                                                                      \
-            INF_TAKE(_d, MAXLEN);                                                             \
-            (void)_d;                                                                         \
-            (OUTSYM) = -2;                                                                    \
-            break;                                                                            \
-        }                                                                                     \
+        if (_m == 0) /* not a code of the set, or the set is empty (MAXLEN 0): dealt with outside */ \
+            INF_LEAVE(WHICH);                                                                 \
         const uint32_t _len = (uint32_t)CTZ64(_m);                                            \
-        if (br.bits < _len) {                                                                 \
-            exhausted = 1;                                                                    \
-            rc = INF_BUF;                                                                     \
-            goto done;                                                                        \
-        }                                                                                     \
+        if (br.bits < _len)                                                                   \
+            INF_ON_EXHAUST;                                                                   \
         const uint32_t _code = _r >> (15 - _len);                                             \
         const uint32_t _ol = (INF_SLOTS > 1 && _len >= GRP) ? GREADLANE(OF2, _len - GRP) : GREADLANE(OF, _len); \
         const uint32_t _fl = (INF_SLOTS > 1 && _len >= GRP) ? GREADLANE(FC2, _len - GRP) : GREADLANE(FC, _len); \
@@ -535,7 +495,7 @@ DEV int inflate_stream(const InfJob &job, InfLds *lds, InfResult *res, InfResume
          * src/inflate.c:1547-1604): find the next 00 00 FF FF -- first in what was left of the
          * bit buffer, then in the input -- and decode on from there as a raw stream: mode =
          * TYPE, empty window, the totals and the check value carry on */
-        pos = flushed = out_base = GUNI(rs->out_pos);
+        pos = out_base = GUNI(rs->out_pos);
         data_errors = GUNI(rs->errors);
         gzip = (int)GUNI(rs->gzip);
         const uint64_t sy0 = ((uint64_t)GUNI(rs->sy_hi) << 32) | GUNI(rs->sy_lo);
@@ -649,17 +609,20 @@ DEV int inflate_stream(const InfJob &job, InfLds *lds, InfResult *res, InfResume
                 can = cap - pos;
                 short_out = 1;
             }
-            /* copy through the staging area, 256 bytes per step */
+            /* 256 bytes per step, into the output and the ring */
             for (uint32_t k = 0; k < can; k += 256u) {
                 const uint32_t step = can - k < 256u ? can - k : 256u;
                 FOR_GLANES
                 {
                     for (uint32_t j = (uint32_t)GLANE; j < step; j += GRP)
-                        lds->stage[(pos + j) & (INF_STAGE - 1)] = src[at + k + j];
+                    {
+                        const uint8_t b = src[at + k + j];
+                        lds->stage[(pos + j) & (INF_STAGE - 1)] = b;
+                        dst[pos + j] = b;
+                    }
                 }
                 WAVE_SYNC();
                 pos += step;
-                INF_FLUSH(0);
             }
             INF_SEEK(at + can);
             if (short_in || short_out) {
@@ -787,39 +750,52 @@ DEV int inflate_stream(const InfJob &job, InfLds *lds, InfResult *res, InfResume
              * copy of the loop without the input / output exhaustion tests, entered while 8 input
              * bytes and 258 output bytes remain, 867 ms against 712 ms -- the second copy of the
              * decoder costs more registers and instruction cache than the dropped tests save.) */
+            uint32_t ev = 0; /* why the symbol loop was left: 0 = end of block, else class << 16 | line */
+#pragma push_macro("INF_ON_EXHAUST")
+#pragma push_macro("INF_ON_FULL")
+#pragma push_macro("INF_BAD")
+#undef INF_ON_EXHAUST
+#undef INF_ON_FULL
+#undef INF_BAD
+#define INF_LEAVE(cls)                              \
+    do {                                            \
+        ev = ((uint32_t)(cls) << 16) | __LINE__;    \
+        goto sym_exit;                              \
+    } while (0)
+#define INF_ON_EXHAUST INF_LEAVE(1)
+#define INF_ON_FULL INF_LEAVE(2)
+#define INF_BAD INF_LEAVE(3)
             for (;;) {
                 int sym;
 #if INF_LIT_LOOP
                 for (;;) {
-                    INF_DECODE_R(&lds->lit, lfc, lof, lfc2, lof2, lmax, lempty, sym);
-                    if ((uint32_t)sym >= 256u) /* a length, the end of the block, or -2 */
+                    INF_DECODE_R(&lds->lit, lfc, lof, lfc2, lof2, lmax, 4, sym);
+                    if (sym >= 256) /* a length or the end of the block */
                         break;
-                    if (pos >= cap) {
-                        rc = INF_BUF;
-                        goto done;
+                    if (pos >= cap)
+                        INF_ON_FULL;
+                    ON_GLANE0
+                    {
+                        lds->stage[pos & (INF_STAGE - 1)] = (uint8_t)sym;
+                        dst[pos] = (uint8_t)sym;
                     }
-                    ON_GLANE0 { lds->stage[pos & (INF_STAGE - 1)] = (uint8_t)sym; }
                     WAVE_SYNC();
                     pos++;
-                    if ((pos & (INF_FLUSH_B - 1u)) == 0)
-                        INF_FLUSH(0);
                 }
-                if (sym == -2)
-                    INF_BAD;
 #else
-                INF_DECODE_R(&lds->lit, lfc, lof, lfc2, lof2, lmax, lempty, sym);
+                INF_DECODE_R(&lds->lit, lfc, lof, lfc2, lof2, lmax, 4, sym);
                 if (sym == -2)
                     INF_BAD;
                 if (sym < 256) {
-                    if (pos >= cap) {
-                        rc = INF_BUF;
-                        goto done;
+                    if (pos >= cap)
+                        INF_ON_FULL;
+                    ON_GLANE0
+                    {
+                        lds->stage[pos & (INF_STAGE - 1)] = (uint8_t)sym;
+                        dst[pos] = (uint8_t)sym;
                     }
-                    ON_GLANE0 { lds->stage[pos & (INF_STAGE - 1)] = (uint8_t)sym; }
                     WAVE_SYNC();
                     pos++;
-                    if ((pos & (INF_FLUSH_B - 1u)) == 0)
-                        INF_FLUSH(0);
                     continue;
                 }
 #endif
@@ -833,7 +809,7 @@ DEV int inflate_stream(const InfJob &job, InfLds *lds, InfResult *res, InfResume
                 INF_TAKE(ex, xb);
                 len = c < 8 ? c + 3u : c == 28 ? 258u : ((4u + ((c - 4u) & 3u)) << ((c - 4u) >> 2)) + 3u + ex;
                 int ds;
-                INF_DECODE_R(&lds->dist, dfc, dof, dfc2, dof2, dmaxlen, dempty, ds);
+                INF_DECODE_R(&lds->dist, dfc, dof, dfc2, dof2, dmaxlen, 5, ds);
                 if (ds < 0 || ds > 29)
                     INF_BAD;
                 xb = ds < 4 ? 0u : ((uint32_t)ds >> 1) - 1u;
@@ -842,10 +818,8 @@ DEV int inflate_stream(const InfJob &job, InfLds *lds, InfResult *res, InfResume
                 const uint32_t dist = (ds < 4 ? (uint32_t)ds : (2u + ((uint32_t)ds & 1u)) << (((uint32_t)ds >> 1) - 1u)) + 1u + ex;
                 if (dist > dmax) /* DISTEXT, :1266-1272 */
                     INF_BAD;
-                if (pos >= cap) { /* MATCH leaves on a full output before it looks at the distance (:1277) */
-                    rc = INF_BUF;
-                    goto done;
-                }
+                if (pos >= cap) /* MATCH leaves on a full output before it looks at the distance (:1277) */
+                    INF_ON_FULL;
                 if (dist > pos - out_base) /* :1279-1288; nothing behind an inflateSync can be copied */
                     INF_BAD;
                 uint32_t can = len;
@@ -864,25 +838,46 @@ DEV int inflate_stream(const InfJob &job, InfLds *lds, InfResult *res, InfResume
                         if (i < can) {
                             const uint32_t q = (uint32_t)(((float)i + 0.5f) * rdist);
                             uint32_t s = pos - dist + (i - q * dist);
-                            /* the ring still holds what was flushed until it is written over: every
-                             * byte less than INF_STAGE before the end of this copy comes from LDS, only
-                             * older ones are read back from the output in global memory */
-                            uint8_t b = (INF_WINDOW ? s + INF_STAGE >= pos + can : s >= flushed) ? lds->stage[s & (INF_STAGE - 1)] : dst[s];
+                            /* every byte less than INF_STAGE before the end of this copy is still in
+                             * the ring; older ones are read back from the output in global memory */
+                            uint8_t b = s + INF_STAGE >= pos + can ? lds->stage[s & (INF_STAGE - 1)] : dst[s];
                             lds->stage[(pos + i) & (INF_STAGE - 1)] = b;
+                            dst[pos + i] = b;
                         }
                     }
                     WAVE_SYNC();
                 }
-                {
-                    const uint32_t before = pos;
-                    pos += can;
-                    if ((before / INF_FLUSH_B) != (pos / INF_FLUSH_B))
-                        INF_FLUSH(0);
+                pos += can;
+                if (can < len)
+                    INF_ON_FULL;
+            }
+        sym_exit:
+#pragma pop_macro("INF_BAD")
+#pragma pop_macro("INF_ON_FULL")
+#pragma pop_macro("INF_ON_EXHAUST")
+#undef INF_LEAVE
+            if (ev != 0) {
+                const uint32_t cls = ev >> 16;
+                if (cls == 1u)
+                    INF_ON_EXHAUST;
+                if (cls == 2u)
+                    INF_ON_FULL;
+                if (cls >= 4u) {
+                    /* the bits were no code of the literal/length (4) or distance (5) set: the
+                     * reference's table has invalid-code markers there, of length 1 for an empty
+                     * set (src/inftrees.c:150-158) and of the longest length otherwise, and drops
+                     * them before it looks at the entry (:1217-1236) */
+                    const uint32_t drop = cls == 4u ? (lempty ? 1u : lmax) : (dempty ? 1u : dmaxlen);
+                    uint32_t dropped;
+                    INF_NEED(drop);
+                    INF_TAKE(dropped, drop);
+                    (void)dropped;
                 }
-                if (can < len) {
-                    rc = INF_BUF;
-                    goto done;
-                }
+                /* a data error (INF_BAD where it happened; the bit reader has not moved since) */
+                sy_start = BR_USED;
+                sy_rb = (8u - (uint32_t)(BR_USED & 7u)) & 7u;
+                fail_line = ev & 0xffffu;
+                goto bad;
             }
         }
         if (last)
@@ -894,7 +889,6 @@ DEV int inflate_stream(const InfJob &job, InfLds *lds, InfResult *res, InfResume
         uint32_t t;
         INF_TAKE(t, br.bits & 7u);
         (void)t;
-        INF_FLUSH(1);
         if (wrap) {
             uint32_t v;
             INF_NEED(32);
@@ -922,7 +916,6 @@ DEV int inflate_stream(const InfJob &job, InfLds *lds, InfResult *res, InfResume
 bad:
     /* a data error: hand the state inflateSync starts from to the next entry */
     data_errors++;
-    INF_FLUSH(1);
     ON_GLANE0
     {
         rs->state = 1;
@@ -937,7 +930,6 @@ bad:
     return 1;
 
 done:
-    INF_FLUSH(1);
     ON_GLANE0
     {
         uint32_t used_bytes = (uint32_t)((BR_USED + 7u) >> 3);
@@ -956,7 +948,6 @@ done:
 #undef INF_BAD
 #undef INF_BADX
 #undef INF_SEEK
-#undef INF_FLUSH
 #undef INF_DECODE
 #undef INF_DECODE_R
 }
