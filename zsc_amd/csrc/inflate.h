@@ -33,9 +33,6 @@
 #ifndef INF_STAGE
 #define INF_STAGE 512u
 #endif
-#ifndef INF_LIT_LOOP
-#define INF_LIT_LOOP 1
-#endif
 static_assert(INF_STAGE >= 512u && (INF_STAGE & (INF_STAGE - 1u)) == 0, "the ring is a power of two and holds the longest match");
 
 template <int NSYM>
@@ -99,6 +96,29 @@ typedef struct {
 
 /* bits consumed so far: every byte pulled into hold, less what is still there */
 #define BR_USED ((uint64_t)br.next * 8u - br.bits)
+
+/* bytes a .. a+3 of the stream as a dword, zero where the stream has ended.  On the GPU the last,
+ * partial dword is read whole and masked: streams start on 16-byte boundaries and 64 readable bytes
+ * follow the last one (include/zsc_hip.h), so the read stays inside mapped memory; the host
+ * emulation reads exactly the stream's bytes. */
+DEV uint32_t inf_input_dword(const uint8_t *src, uint32_t a, uint32_t n)
+{
+#ifdef ZSC_WAVE_EMU
+    uint32_t v = 0;
+    if (a + 4 <= n)
+        v = ld_u32(src + a);
+    else
+        for (uint32_t j = 0; j < 4; j++)
+            if (a + j < n)
+                v |= (uint32_t)src[a + j] << (8 * j);
+    return v;
+#else
+    if (a >= n)
+        return 0;
+    const uint32_t v = ld_u32(src + a);
+    return n - a >= 4u ? v : v & ((1u << (8u * (n - a))) - 1u);
+#endif
+}
 
 #define INF_OK 0
 #define INF_END 1
@@ -257,18 +277,7 @@ DEV int inflate_stream(const InfJob &job, InfLds *lds, InfResult *res, InfResume
     br.next = 0;
     br.chunk_at = 0;
     LANEVAR(uint32_t, cur); /* dword GLANE of the current 256-byte input chunk */
-    FOR_GLANES
-    {
-        uint32_t a = 4u * (uint32_t)GLANE;
-        uint32_t v = 0;
-        if (a + 4 <= n)
-            v = ld_u32(src + a);
-        else
-            for (uint32_t j = 0; j < 4; j++)
-                if (a + j < n)
-                    v |= (uint32_t)src[a + j] << (8 * j);
-        LV(cur) = v;
-    }
+    FOR_GLANES { LV(cur) = inf_input_dword(src, 4u * (uint32_t)GLANE, n); }
 
     const int resumed = GUNI(rs->state) == 1u;
     uint32_t pos = 0; /* output bytes produced (each is stored to dst as it is made) */
@@ -290,15 +299,7 @@ DEV int inflate_stream(const InfJob &job, InfLds *lds, InfResult *res, InfResume
                 br.chunk_at += INF_CHUNK;                                                          \
                 FOR_GLANES                                                                     \
                 {                                                                             \
-                    uint32_t _a = br.chunk_at + 4u * (uint32_t)GLANE;                          \
-                    uint32_t _v = 0;                                                          \
-                    if (_a + 4 <= n)                                                          \
-                        _v = ld_u32(src + _a);                                                \
-                    else                                                                      \
-                        for (uint32_t _j = 0; _j < 4; _j++)                                   \
-                            if (_a + _j < n)                                                  \
-                                _v |= (uint32_t)src[_a + _j] << (8 * _j);                     \
-                    LV(cur) = _v;                                                             \
+                    LV(cur) = inf_input_dword(src, br.chunk_at + 4u * (uint32_t)GLANE, n);     \
                 }                                                                             \
             }                                                                                 \
             const uint32_t _o = br.next - br.chunk_at;                                        \
@@ -384,15 +385,7 @@ DEV int inflate_stream(const InfJob &job, InfLds *lds, InfResult *res, InfResume
             br.chunk_at = br.next & ~(INF_CHUNK - 1u);                                                    \
             FOR_GLANES                                                                         \
             {                                                                                 \
-                uint32_t _a = br.chunk_at + 4u * (uint32_t)GLANE;                              \
-                uint32_t _w = 0;                                                              \
-                if (_a + 4 <= n)                                                              \
-                    _w = ld_u32(src + _a);                                                    \
-                else                                                                          \
-                    for (uint32_t _j = 0; _j < 4; _j++)                                       \
-                        if (_a + _j < n)                                                      \
-                            _w |= (uint32_t)src[_a + _j] << (8 * _j);                         \
-                LV(cur) = _w;                                                                 \
+                LV(cur) = inf_input_dword(src, br.chunk_at + 4u * (uint32_t)GLANE, n);         \
             }                                                                                 \
         }                                                                                     \
     } while (0)
@@ -454,7 +447,9 @@ DEV int inflate_stream(const InfJob &job, InfLds *lds, InfResult *res, InfResume
  * one LDS read per symbol instead of five. */
 #define INF_DECODE_R(C, FC, OF, FC2, OF2, MAXLEN, WHICH, OUTSYM)                               \
     do {                                                                                      \
-        if (br.bits < 15)                                                                     \
+        /* topped up to more than 32 bits here (or to the end of the input), the code and the \
+         * extra bits behind it (15 + 13 at most) need no second look at the input */         \
+        if (br.bits <= 32)                                                                    \
             INF_REFILL();                                                                     \
         const uint32_t _peek = (uint32_t)br.hold & 0x7fffu;                                   \
         const uint32_t _r = BREV32(_peek) >> 17; /* the 15 bits MSB first */                  \
@@ -745,11 +740,15 @@ DEV int inflate_stream(const InfJob &job, InfLds *lds, InfResult *res, InfResume
             }
             const uint32_t lmax = GUNI(lds->lit.max_len), lempty = GUNI(lds->lit.empty);
             const uint32_t dmaxlen = GUNI(lds->dist.max_len), dempty = GUNI(lds->dist.empty);
-            /* (Two restructurings of this loop were measured on BASELINE config 4 and dropped: literal
-             * runs as an inner loop of their own, 780 ms against 720 ms; and an inflate_fast-style
-             * copy of the loop without the input / output exhaustion tests, entered while 8 input
-             * bytes and 258 output bytes remain, 867 ms against 712 ms -- the second copy of the
-             * decoder costs more registers and instruction cache than the dropped tests save.) */
+            /* The symbol loop.  Its shape matters more than its instruction count suggests: with the
+             * error exits as gotos to the function's exit code the compiler threaded a dispatch
+             * variable and copies of the live state through every join (~40 % of the vector
+             * instructions); now every way out of the loop is the ONE exit below with an event
+             * code, output bytes go straight to dst, and what is rare (a code that is none, the
+             * exit bookkeeping) happens outside.  Literal runs are an inner loop, so that the
+             * groups of a wave that have reached a match go through the match path together.
+             * (Measured and dropped: an inflate_fast-style second copy of the loop without the
+             * exhaustion tests -- more registers and code than the tests cost.) */
             uint32_t ev = 0; /* why the symbol loop was left: 0 = end of block, else class << 16 | line */
 #pragma push_macro("INF_ON_EXHAUST")
 #pragma push_macro("INF_ON_FULL")
@@ -767,7 +766,6 @@ DEV int inflate_stream(const InfJob &job, InfLds *lds, InfResult *res, InfResume
 #define INF_BAD INF_LEAVE(3)
             for (;;) {
                 int sym;
-#if INF_LIT_LOOP
                 for (;;) {
                     INF_DECODE_R(&lds->lit, lfc, lof, lfc2, lof2, lmax, 4, sym);
                     if (sym >= 256) /* a length or the end of the block */
@@ -782,30 +780,14 @@ DEV int inflate_stream(const InfJob &job, InfLds *lds, InfResult *res, InfResume
                     WAVE_SYNC();
                     pos++;
                 }
-#else
-                INF_DECODE_R(&lds->lit, lfc, lof, lfc2, lof2, lmax, 4, sym);
-                if (sym == -2)
-                    INF_BAD;
-                if (sym < 256) {
-                    if (pos >= cap)
-                        INF_ON_FULL;
-                    ON_GLANE0
-                    {
-                        lds->stage[pos & (INF_STAGE - 1)] = (uint8_t)sym;
-                        dst[pos] = (uint8_t)sym;
-                    }
-                    WAVE_SYNC();
-                    pos++;
-                    continue;
-                }
-#endif
                 if (sym == 256)
                     break;
                 if (sym > 285)
                     INF_BAD;
                 uint32_t c = (uint32_t)sym - 257u, xb, ex, len;
                 xb = (c < 8 || c == 28) ? 0u : (c - 4u) >> 2;
-                INF_NEED(xb);
+                if (br.bits < xb) /* (the top-up before the code took what input there was) */
+                    INF_ON_EXHAUST;
                 INF_TAKE(ex, xb);
                 len = c < 8 ? c + 3u : c == 28 ? 258u : ((4u + ((c - 4u) & 3u)) << ((c - 4u) >> 2)) + 3u + ex;
                 int ds;
@@ -813,7 +795,8 @@ DEV int inflate_stream(const InfJob &job, InfLds *lds, InfResult *res, InfResume
                 if (ds < 0 || ds > 29)
                     INF_BAD;
                 xb = ds < 4 ? 0u : ((uint32_t)ds >> 1) - 1u;
-                INF_NEED(xb);
+                if (br.bits < xb) /* (the top-up before the code took what input there was) */
+                    INF_ON_EXHAUST;
                 INF_TAKE(ex, xb);
                 const uint32_t dist = (ds < 4 ? (uint32_t)ds : (2u + ((uint32_t)ds & 1u)) << (((uint32_t)ds >> 1) - 1u)) + 1u + ex;
                 if (dist > dmax) /* DISTEXT, :1266-1272 */
