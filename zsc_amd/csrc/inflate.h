@@ -782,29 +782,37 @@ DEV int inflate_stream(const InfJob &job, InfLds *lds, InfResult *res, InfResume
                 }
                 if (sym == 256)
                     break;
-                if (sym > 285)
-                    INF_BAD;
+                /* What can end the symbol before its copy is tested once per code, in straight-line
+                 * code; which of the reasons it was, in the reference's order, is sorted out in the
+                 * (cold) block behind the test. */
                 uint32_t c = (uint32_t)sym - 257u, xb, ex, len;
-                xb = (c < 8 || c == 28) ? 0u : (c - 4u) >> 2;
-                if (br.bits < xb) /* (the top-up before the code took what input there was) */
-                    INF_ON_EXHAUST;
+                xb = (c < 8 || c >= 28) ? 0u : (c - 4u) >> 2;
+                if ((sym > 285) | (br.bits < xb)) {
+                    if (sym > 285)
+                        INF_BAD;
+                    INF_ON_EXHAUST; /* (the top-up before the code took what input there was) */
+                }
                 INF_TAKE(ex, xb);
                 len = c < 8 ? c + 3u : c == 28 ? 258u : ((4u + ((c - 4u) & 3u)) << ((c - 4u) >> 2)) + 3u + ex;
                 int ds;
                 INF_DECODE_R(&lds->dist, dfc, dof, dfc2, dof2, dmaxlen, 5, ds);
-                if (ds < 0 || ds > 29)
-                    INF_BAD;
-                xb = ds < 4 ? 0u : ((uint32_t)ds >> 1) - 1u;
-                if (br.bits < xb) /* (the top-up before the code took what input there was) */
-                    INF_ON_EXHAUST;
+                const uint32_t dsu = (uint32_t)ds; /* 0..31 */
+                xb = dsu < 4 ? 0u : (dsu >> 1) - 1u;
+                const uint32_t dist = (dsu < 4 ? dsu : (2u + (dsu & 1u)) << ((dsu >> 1) - 1u)) + 1u +
+                                      ((uint32_t)br.hold & ((1u << xb) - 1u));
+                if ((dsu > 29u) | (br.bits < xb) | (dist > dmax) | (pos >= cap) | (dist > pos - out_base)) {
+                    if (dsu > 29u)
+                        INF_BAD;
+                    if (br.bits < xb)
+                        INF_ON_EXHAUST;
+                    INF_TAKE(ex, xb);
+                    if (dist > dmax) /* DISTEXT, :1266-1272 */
+                        INF_BAD;
+                    if (pos >= cap) /* MATCH leaves on a full output before it looks at the distance (:1277) */
+                        INF_ON_FULL;
+                    INF_BAD; /* :1279-1288; nothing behind an inflateSync can be copied */
+                }
                 INF_TAKE(ex, xb);
-                const uint32_t dist = (ds < 4 ? (uint32_t)ds : (2u + ((uint32_t)ds & 1u)) << (((uint32_t)ds >> 1) - 1u)) + 1u + ex;
-                if (dist > dmax) /* DISTEXT, :1266-1272 */
-                    INF_BAD;
-                if (pos >= cap) /* MATCH leaves on a full output before it looks at the distance (:1277) */
-                    INF_ON_FULL;
-                if (dist > pos - out_base) /* :1279-1288; nothing behind an inflateSync can be copied */
-                    INF_BAD;
                 uint32_t can = len;
                 if (can > cap - pos)
                     can = cap - pos;
