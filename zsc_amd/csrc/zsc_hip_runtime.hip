@@ -2316,6 +2316,12 @@ extern "C" ZlibReturn zsc_hip_inflate_plan_create(zsc_hip_inflate_plan **plan_ou
         items[i].src_len = source_lens[i];
         items[i].dst_cap = dest_caps[i];
         order[i] = i;
+        if ((src_offsets[i] | dst_offsets[i]) & 15u) {
+            /* (the decoder reads a stream's last, partial dword whole: it must not straddle a page) */
+            ZSC_WARN1("zsc_hip: stream %u is not 16-byte aligned in the batch.", i);
+            delete pl;
+            return Z_STREAM_ERROR;
+        }
     }
     std::stable_sort(order.begin(), order.end(),
                      [&](uint32_t a, uint32_t b) { return items[a].dst_cap > items[b].dst_cap; });
