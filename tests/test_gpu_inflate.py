@@ -88,6 +88,29 @@ def test_config4_many_gzip_chunks(z, oracle):
     assert outs == plain * reps
 
 
+def test_more_streams_than_the_grid_holds_and_plan_alignment(z, oracle):
+    """The decoder's groups take streams from one queue: with more streams than resident groups
+    (256 CUs x 20 waves x 4) every group decodes several, of different kinds and lengths, one
+    after the other in the same LDS.  And: a plan refuses offsets that are not multiples of 16."""
+    import ctypes as C
+    kinds = ("text", "token", "table", "zero", "random")
+    plain = [corpus.make_buffer(kinds[i % len(kinds)], 1 + (i * 37) % 700, 900 + i) for i in range(48)]
+    gz = [oracle.compress(b, (1, 6, 9)[i % 3], window_bits=(15, 31, -15)[i % 3])[1] for i, b in enumerate(plain)]
+    for wb in (15, 31, -15):
+        idx = [i for i in range(48) if (15, 31, -15)[i % 3] == wb]
+        reps = 100000 // len(idx) + 1                  # > 81 920 resident groups
+        srcs = [gz[i] for i in idx] * reps
+        caps = [len(plain[i]) for i in idx] * reps
+        rc, outs, _, stats = z.uncompress_batch(srcs, caps, window_bits=wb)
+        assert rc == 0 and all(s == 0 for s in stats)
+        want = [plain[i] for i in idx]
+        assert all(outs[k] == want[k % len(idx)] for k in range(len(outs)))
+    h = C.c_void_p()
+    rc = z.lib.zsc_hip_inflate_plan_create(C.byref(h), 2, (C.c_uint32 * 2)(10, 10), (C.c_uint64 * 2)(0, 88),
+                                           (C.c_uint32 * 2)(100, 100), (C.c_uint64 * 2)(0, 176), 15)
+    assert rc == -2 and not h.value
+
+
 def test_resynchronisation_after_data_errors(z, oracle):
     """damaged multi-section streams written by the reference; zsc_uncompress
     finds the next full-flush marker (inflateSync) and salvages what follows.  Expected code,
