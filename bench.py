@@ -524,7 +524,9 @@ def main() -> None:
                          "launches_per_step": plan.sub_batches, "achieved": round(achieved, 3),
                          "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": round(achieved / HBM_PEAK_GBS, 6), "traffic": None,
-                         "algorithmic_bytes_per_launch": alg_bytes,
+                         "algorithmic_bytes_per_step": alg_bytes,
+                         "note": "achieved = algorithmic bytes of one step / the kernel's time in that step (both "
+                                 "sums over the step's launches, one per sub-batch); traffic likewise per step",
                          "kernel_ms": {k: round(v, 3) for k, v in ktimes.items()}},
             "scratch_bytes": plan.scratch_bytes,
             "checked": checked,
@@ -561,6 +563,14 @@ def main() -> None:
             info, members, outs = bench_inflate(dev, stream, args.inflate_streams, args.inflate_distinct, fence, orders)
             if len(orders) == 1:
                 info.pop("identical_neighbours")
+            try:  # HBM traffic of k_inflate from the PMC passes, scaled by output bytes
+                pi = json.load(open(os.path.join(ROOT, "profiles", "pmc_traffic.json")))["inflate"]
+                if pi["order"] == info["order"]:
+                    sc = info["output_bytes"] / pi["output_bytes"]
+                    info["roofline"]["traffic"] = round((pi["fetch_kb"] * pi["fetch_scale"] + pi["write_kb"]) * 1024 * sc)
+                    info["roofline"]["traffic_note"] = pi["note"]
+            except Exception:
+                pass
             if not args.no_cpu_baseline:
                 info["cpu_baseline"] = cpu_inflate_baseline(members, outs)
             line["inflate"] = info
