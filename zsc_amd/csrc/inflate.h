@@ -1,5 +1,6 @@
 /*
- * inflate.h -- kernel 5: DEFLATE decoding, one wavefront per stream.
+ * inflate.h -- kernel 5: DEFLATE decoding, one GROUP of lanes per stream (16 lanes on the GPU:
+ * four streams share a wavefront; wave_group.h).
  *
  * Restates the reference's inflate() state machine for one-shot use
  * (src/inflate.c:704-1404: header :740-954, block type :975-1009, stored :1010-1049,
@@ -9,18 +10,22 @@
  * (src/zsc_uncompr.c:44-154).
  *
  * Decoding one stream is bit-serial, so the parallelism is across streams (config
- * 4 has a million of them) plus, inside the wave:
+ * 4 has a million of them) plus, inside the group:
  *   - Huffman decoding without lookup tables: the next 15 bits are bit-reversed so
  *     the code sits MSB-first, lane l tests "is the code one of the length-l codes"
- *     (code_l - first[l] < count[l]); the lowest set bit of the ballot is the code
- *     length.  Decoder state is ~0.8 KiB of LDS per wave (not zlib's 5.8 KiB of
- *     tables), so 32 waves fit a CU and latency is hidden by occupancy;
+ *     (code_l - first[l] < count[l]); the lowest set bit of the group's ballot slice is
+ *     the code length.  Decoder state is 1.7 KiB of LDS per stream (not zlib's 5.8 KiB
+ *     of tables): 20 waves = 80 streams per CU;
  *   - match copies are lane-parallel even when source and destination overlap:
  *     byte i of a copy comes from pos - dist + (i mod dist), which always lies
  *     before the copy's first byte;
- *   - input is consumed from a 256-byte chunk held across the lanes of one VGPR
- *     (readlane), output goes through a 1 KiB LDS staging area and leaves as
- *     coalesced stores.
+ *   - input is consumed from a 64-byte chunk held across the lanes of one VGPR
+ *     (ds_bpermute); every output byte is stored to dst as it is made and kept in a
+ *     512-byte LDS ring, from which near matches are copied (farther ones are read
+ *     back from dst).
+ * Group-uniform values live in vector registers, so the four groups of a wave share the
+ * instruction stream where their paths agree; the symbol loop is shaped for that (one exit,
+ * literal runs as an inner loop; see the comment there and DESIGN.md 5b).
  * Byte counts follow the reference: bytes are "consumed" once pulled into the bit
  * buffer, which for both its fast and slow paths is ceil(bits used / 8).
  */
@@ -46,12 +51,12 @@ struct InfCodeT {
     uint32_t empty;
 };
 
-/* per stream: 1.7 KiB with a 512-byte stage, so that four streams per wave (+ the CRC table)
- * leave room for twenty waves on a CU (measured on BASELINE config 4: 12 waves 30.4 GB/s, 16 waves
- * 40.9, 20 waves 43.2 -- by then the vector ALUs are the limit).  The code-length code is dead once the lengths are read, before the distance
- * code is built, and shares its place; the CRC routine's exchange area lies in the stage, which
- * is empty whenever a check value is computed (gzip header: nothing decoded yet; trailer: after
- * the final flush). */
+/* per stream: 1.7 KiB with a 512-byte ring, so that four streams per wave (+ the CRC table) leave
+ * room for twenty waves on a CU (measured on BASELINE config 4: 12 waves 30.4 GB/s, 16 waves 40.9,
+ * 20 waves 43.2 -- by then the vector ALUs are the limit).  The code-length code is dead once the
+ * lengths are read, before the distance code is built, and shares its place; the CRC routine's
+ * exchange area lies in the ring, which is not needed whenever a check value is computed (gzip
+ * header: nothing decoded yet; trailer: nothing left to decode). */
 typedef struct {
     InfCodeT<288> lit;
     union {
