@@ -30,6 +30,7 @@
 #include "zsc_dev.h"
 
 #define LZ_PR 512u /* positions covered by the rank/hib look-ahead ring */
+#define LZ_PR_FAST 128u /* the same in the greedy parser's LDS */
 
 /* LDS of the lazy parser (levels 4-9): 36 KiB window ring + look-ahead rings = 39 680 B,
  * four waves per CU */
@@ -38,6 +39,7 @@ struct LzLdsT {
     static constexpr uint32_t RING = RING_BYTES, CHUNK = CHUNK_BYTES;
     static constexpr bool HAS_INS = WITH_HOLES; /* lz_load_chunk clears ins[] for what enters the ring */
     static constexpr bool HOLES = WITH_HOLES;
+    static constexpr uint32_t PR = LZ_PR;
     uint8_t ring[RING + 512]; /* sliding window; first 16 bytes mirrored after the end, rest slack for masked over-reads */
     uint32_t stage[WAVE];     /* symbols waiting for a coalesced store */
     uint16_t prank[LZ_PR];    /* rank[] of the next few hundred positions */
@@ -65,9 +67,15 @@ struct LzLdsFast {
     static constexpr uint32_t RING = 34816u, CHUNK = 2048u;
     static constexpr bool HAS_INS = true;
     static constexpr bool HOLES = false;
+    static constexpr uint32_t PR = LZ_PR_FAST;
     uint8_t ring[RING + 512];
     uint32_t stage[WAVE];
     uint32_t ins[RING / 32];  /* bit r: the position at ring index r is in the hash chains */
+    /* rank[] / hib[] of the next positions, 64 per coalesced load (as the lazy parser's prank / phib,
+     * but 128 entries: with 512 the fifth KiB would cost the fourth wave of a CU) -- reading them from
+     * global memory position by position was a dependent round trip per searched position */
+    uint16_t prank[LZ_PR_FAST];
+    uint16_t phib[LZ_PR_FAST];
 };
 
 typedef struct {
@@ -330,8 +338,8 @@ DEV void lz_ensure_ranks(const LzJob &job, L *lds, LzState &st, uint32_t p)
     do {                                                                                      \
         const uint32_t _t = (x) >> 15;                                                        \
         const uint32_t *_ra = job.sorted + (uint64_t)_t * ZD_TILE;                            \
-        const int32_t _ha = (int32_t)UNI(lds->prank[(x) & (LZ_PR - 1)]) - 1;                  \
-        const int32_t _hb = _t ? (int32_t)(int16_t)UNI(lds->phib[(x) & (LZ_PR - 1)]) : -1;    \
+        const int32_t _ha = (int32_t)UNI(lds->prank[(x) & (L::PR - 1)]) - 1;                  \
+        const int32_t _hb = _t ? (int32_t)(int16_t)UNI(lds->phib[(x) & (L::PR - 1)]) : -1;    \
         FOR_LANES                                                                             \
         {                                                                                     \
             int32_t _ia = _ha - LANE, _ib = _hb - LANE;                                       \
@@ -762,6 +770,15 @@ DEV void lz_parse_greedy(const LzJob &job, LzLdsFast *lds)
 
     uint32_t p = 0, len = 0, at = 0;
     uint32_t owed = 0; /* s->insert: strings at the end of a section that wait for their third byte */
+    /* first candidate batches of the position being searched (c) and of the next one (n), asked for
+     * one search ahead as in the lazy parser: after a literal the parse goes to p + 1.  (Three
+     * positions ahead in three register slots was slower, 864 against 749 ms on BASELINE config 3:
+     * the compiler waits for all outstanding loads where one slot is used.) */
+    LANEVAR(uint32_t, cA);
+    LANEVAR(uint32_t, cB);
+    LANEVAR(uint32_t, nA);
+    LANEVAR(uint32_t, nB);
+    uint32_t n_at = 0xffffffffu;
     for (;;) {
         st.it = p;
         uint32_t look = st.data_end - p;
@@ -808,13 +825,41 @@ DEV void lz_parse_greedy(const LzJob &job, LzLdsFast *lds)
 
             const uint32_t tile = p >> 15;
             const uint32_t *runA = job.sorted + (uint64_t)tile * ZD_TILE;
-            const int32_t hiA = (int32_t)UNI(job.rank[p]) - 1;
-            const int32_t hiB = tile ? (int32_t)(int16_t)UNI(job.hib[p]) : -1;
+            if (st.pr_hi <= p)
+                st.pr_hi = p & ~(uint32_t)(WAVE - 1); /* (a long match was jumped over) */
+            while (st.pr_hi <= p || (st.pr_hi < job.ntot && st.pr_hi < p + (LZ_PR_FAST - WAVE))) {
+                FOR_LANES
+                {
+                    const uint32_t x = st.pr_hi + (uint32_t)LANE;
+                    if (x < job.ntot) {
+                        lds->prank[x & (LZ_PR_FAST - 1)] = job.rank[x];
+                        lds->phib[x & (LZ_PR_FAST - 1)] = job.hib[x];
+                    }
+                }
+                WAVE_SYNC();
+                st.pr_hi += WAVE;
+            }
+            const int32_t hiA = (int32_t)UNI(lds->prank[p & (LZ_PR_FAST - 1)]) - 1;
+            const int32_t hiB = tile ? (int32_t)(int16_t)UNI(lds->phib[p & (LZ_PR_FAST - 1)]) : -1;
+            if (p == n_at) {
+                FOR_LANES { LV(cA) = LV(nA); LV(cB) = LV(nB); }
+            } else {
+                LZ_FETCH_FIRST(p, cA, cB);
+            }
+            n_at = 0xffffffffu;
+            if (p + 4 <= st.n && p + 1 < st.pr_hi) { /* p + 1 owns a string and its rank is staged */
+                n_at = p + 1;
+                LZ_FETCH_FIRST(n_at, nA, nB);
+            }
             int verdict = 0;
-            LZ_WALK_RUN(runA, hiA + WAVE, tile << 15, LZ_MEMB_INS, verdict);
+            LZ_EVAL_BATCH(cA, tile << 15, LZ_MEMB_INS, verdict);
+            if (verdict == 0)
+                LZ_WALK_RUN(runA, hiA, tile << 15, LZ_MEMB_INS, verdict);
             if (verdict == 1 && tile != 0) {
                 verdict = 0;
-                LZ_WALK_RUN(runA - ZD_TILE, hiB + WAVE, (tile - 1) << 15, LZ_MEMB_INS, verdict);
+                LZ_EVAL_BATCH(cB, (tile - 1) << 15, LZ_MEMB_INS, verdict);
+                if (verdict == 0)
+                    LZ_WALK_RUN(runA - ZD_TILE, hiB, (tile - 1) << 15, LZ_MEMB_INS, verdict);
             }
             if (verdict != 3 && sc.head_seen) {
                 at = sc.where;
