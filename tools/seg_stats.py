@@ -38,3 +38,6 @@ par = sum(sched(s["q"]) + sum(x + 8 for x in s["redo"]) for s in steps)
 ser = tot_q + tot_r + 8 * (nq + nredo)
 print(f"{kind} n={size} L{level}: steps {len(steps)} queue segs {nq} redo segs {nredo} batches queue {tot_q} redo {tot_r} "
       f"long compares {cnt[1]}  batch/byte {(tot_q+tot_r)/size:.3f}  ideal speed-up on {waves} waves {ser/par:.2f}")
+# the same if the re-parsed segments had been ordinary queue segments (no serial phases)
+par2 = sum(sched(s["q"] + s["redo"]) for s in steps)
+print(f"  without serial re-parses: ideal speed-up {ser/par2:.2f}; serial re-parse share of the schedule {sum(sum(x + 8 for x in s['redo']) for s in steps)/par:.2f}")
