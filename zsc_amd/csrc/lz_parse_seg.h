@@ -14,10 +14,13 @@
  *     of the position alone, so a parser that stands at position x with NO match
  *     pending ("fresh": match_available == 0, match_length == 2) continues
  *     identically whatever happened before x;
+ *     and so does one with no match pending that still owes the literal of the byte before
+ *     x ("neutral": match_available == 1, match_length == 2 -- the state of every position
+ *     inside a run of literals; without it incompressible data never hands over);
  *   - every segment's parser starts fresh at the segment start and records every
- *     position it visits fresh (a bitmap in LDS, plus its token count there);
- *   - a parser keeps going past the end of its segment until it is fresh at a position
- *     the parser of the segment it has run into also visited fresh: from there on that
+ *     position it visits fresh or neutral (two bitmaps in LDS, plus its token count there);
+ *   - a parser keeps going past the end of its segment until it stands at a position in
+ *     the state the parser of the segment it has run into also had there: from there on that
  *     parser's tokens ARE the serial parse's tokens.  Text resyncs within a few tokens;
  *   - if no common position turns up within SG_OV bytes (a long run, say), the parser
  *     stops with its exact state, and once the chain of hand-overs has reached it wave
@@ -90,6 +93,7 @@ struct SgLds {
     static constexpr bool HAS_INS = false;
     uint8_t ring[RING + 512];
     uint32_t trace[SG_NS][SG_TRACE / 32];
+    uint32_t tkind[SG_NS][SG_TRACE / 32]; /* for the positions in trace: 1 = a literal was owed there */
     SgWave wv[SG_NS];             /* one record per segment of the super-step */
     /* workgroup state */
     uint32_t S0;                  /* first position of the current super-step */
@@ -545,7 +549,7 @@ DEV void sg_parse_segment(const LzJob &job, SgLds *lds, const SgScratch &scr, ui
     uint32_t lit = 0;                      /* the byte at p-1 */
     if (pending)
         lit = GUNI(lds->ring[lz_ridx<L>(st, p - 1u)]);
-    uint32_t tw = 0, tw_idx = 0xffffffffu; /* trace word being filled */
+    uint32_t tw = 0, tk = 0, tw_idx = 0xffffffffu; /* trace word (and its kind bits) being filled */
     uint32_t sd_blk = 0xffffffffu;         /* 64-position block sdx belongs to */
 
     for (;;) {
@@ -559,7 +563,8 @@ DEV void sg_parse_segment(const LzJob &job, SgLds *lds, const SgScratch &scr, ui
             }
         }
         SG_COUNT(4, 1);
-        const int fresh = ((uint32_t)pending | (cur_len ^ 2u)) == 0;
+        /* no match pending: the state is (p, pending) alone -- fresh or neutral */
+        const int fresh = cur_len == 2u;
         if (p >= e_s) {
             if (p >= E) {
                 exit_kind = SG_EXIT_LAST;
@@ -568,7 +573,8 @@ DEV void sg_parse_segment(const LzJob &job, SgLds *lds, const SgScratch &scr, ui
             if (fresh) {
                 /* the segment p lies in recorded the positions its own parser was fresh at */
                 const uint32_t t = (p - S0) / SG_G, r = (p - S0) % SG_G;
-                if ((GUNI(lds->trace[t][r >> 5]) >> (r & 31u)) & 1u) {
+                if (((GUNI(lds->trace[t][r >> 5]) >> (r & 31u)) & 1u) &&
+                    ((GUNI(lds->tkind[t][r >> 5]) >> (r & 31u)) & 1u) == (uint32_t)pending) {
                     exit_kind = SG_EXIT_SYNCED;
                     break;
                 }
@@ -581,12 +587,17 @@ DEV void sg_parse_segment(const LzJob &job, SgLds *lds, const SgScratch &scr, ui
             const uint32_t r = p - a_s;
             if ((r >> 5) != tw_idx) {
                 if (tw_idx != 0xffffffffu) {
-                    ON_GLANE0 { lds->trace[s][tw_idx] = tw; }
+                    ON_GLANE0
+                    {
+                        lds->trace[s][tw_idx] = tw;
+                        lds->tkind[s][tw_idx] = tk;
+                    }
                 }
                 tw_idx = r >> 5;
-                tw = 0;
+                tw = tk = 0;
             }
             tw |= 1u << (r & 31u);
+            tk |= (uint32_t)pending << (r & 31u);
             if (r / GRP != sd_blk) {
                 if (sd_blk != 0xffffffffu) {
                     FOR_GLANES { sidx[sd_blk * GRP + (uint32_t)GLANE] = (uint16_t)LV(sdx); }
@@ -762,8 +773,10 @@ DEV void sg_parse_segment(const LzJob &job, SgLds *lds, const SgScratch &scr, ui
     }
     ON_GLANE0
     {
-        if (tw_idx != 0xffffffffu)
+        if (tw_idx != 0xffffffffu) {
             lds->trace[s][tw_idx] = tw;
+            lds->tkind[s][tw_idx] = tk;
+        }
         SgWave *me = &lds->wv[s];
         me->exit_kind = exit_kind;
         me->exit_p = p;
