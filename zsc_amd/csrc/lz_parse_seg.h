@@ -573,7 +573,9 @@ DEV void sg_parse_segment(const LzJob &job, SgLds *lds, const SgScratch &scr, ui
             if (fresh) {
                 /* the segment p lies in recorded the positions its own parser was fresh at */
                 const uint32_t t = (p - S0) / SG_G, r = (p - S0) % SG_G;
-                if (((GUNI(lds->trace[t][r >> 5]) >> (r & 31u)) & 1u) &&
+                /* (the other parser may still be running: its words are published kinds first) */
+                const uint32_t tword = GUNI(LDS_LOAD_ACQ(&lds->trace[t][r >> 5]));
+                if (((tword >> (r & 31u)) & 1u) &&
                     ((GUNI(lds->tkind[t][r >> 5]) >> (r & 31u)) & 1u) == (uint32_t)pending) {
                     exit_kind = SG_EXIT_SYNCED;
                     break;
@@ -589,8 +591,9 @@ DEV void sg_parse_segment(const LzJob &job, SgLds *lds, const SgScratch &scr, ui
                 if (tw_idx != 0xffffffffu) {
                     ON_GLANE0
                     {
-                        lds->trace[s][tw_idx] = tw;
+                        /* kinds first: whoever sees a bit of the trace word finds its kind in place */
                         lds->tkind[s][tw_idx] = tk;
+                        LDS_STORE_REL(&lds->trace[s][tw_idx], tw);
                     }
                 }
                 tw_idx = r >> 5;
@@ -774,8 +777,8 @@ DEV void sg_parse_segment(const LzJob &job, SgLds *lds, const SgScratch &scr, ui
     ON_GLANE0
     {
         if (tw_idx != 0xffffffffu) {
-            lds->trace[s][tw_idx] = tw;
             lds->tkind[s][tw_idx] = tk;
+            LDS_STORE_REL(&lds->trace[s][tw_idx], tw);
         }
         SgWave *me = &lds->wv[s];
         me->exit_kind = exit_kind;
