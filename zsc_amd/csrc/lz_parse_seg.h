@@ -65,7 +65,9 @@
 #define SG_MIN_WAVES 6 /* waves per SIMD the register allocation aims at (three workgroups per CU) */
 #endif
 #define SG_NS (SG_SPAN / SG_G)      /* segments per super-step, handed to the waves by a work queue */
+#ifndef SG_OV
 #define SG_OV 512u                  /* how far past its segment a parser looks for a hand-over */
+#endif
 #define SG_TRACE SG_G               /* positions a segment records (its own) */
 #define SG_TOKCAP (SG_G + SG_OV + 320u) /* tokens one segment's parser can emit */
 
