@@ -1125,6 +1125,11 @@ static ZlibReturn plan_create(zsc_hip_deflate_plan **plan_out, U32 count, const 
                 blk_owner[b.blk0 + s] = k;
             order[k] = k;
         }
+        /* buffers longer than this go to the segmented parser.  Measured on the x4096 batch: 18 432
+         * (round 1: what fits the small rings stays with the wave-per-buffer parser) 2 843 + 37 ms of
+         * parsing, 8 192: 2 853 + 13 ms, 3 072: 2 853 + 0 ms -- a workgroup per 4 KiB file still
+         * beats a wave per file */
+        static const uint32_t seg_min = getenv("ZSC_HIP_SEG_MIN") ? (uint32_t)atoi(getenv("ZSC_HIP_SEG_MIN")) : 3072u;
         /* longest first; among the long ones, those the lane-per-segment parser takes come
          * first, then those the segmented parser may take */
         auto lane_able = [&](uint32_t k) {
@@ -1133,7 +1138,7 @@ static ZlibReturn plan_create(zsc_hip_deflate_plan **plan_out, U32 count, const 
         };
         auto seg_able = [&](uint32_t k) {
             const ZdBuf &b = pl->bufs[sb.first + k];
-            return pl->use_seg && b.in_len > 18432u && (b.sched_n == 0 || b.seg_ok);
+            return pl->use_seg && b.in_len > seg_min && (b.sched_n == 0 || b.seg_ok);
         };
         auto klass = [&](uint32_t k) { return lane_able(k) ? 0 : seg_able(k) ? 1 : 2; };
         std::stable_sort(order.begin(), order.end(), [&](uint32_t a, uint32_t c) {
