@@ -126,12 +126,12 @@ ZlibReturn zsc_hip_deflate_plan_results(zsc_hip_deflate_plan *plan, U32 *dest_le
 
 /* Per-kernel device time in milliseconds, measured with HIP events recorded on the
  * run's stream and averaged over every run since profiling was switched on:
- * index 0 checksum, 1 hash sort, 2 parse (the segmented multi-wave kernel at levels 4-9,
- * the greedy kernel at levels 1-3), 3 parse of buffers under 18 KiB (wave-per-buffer kernels,
- * levels 4-9), 4 huffman plan, 5 layout, 6 bit emit, 7 whole pass.  A plan that had to be
+ * index 0 checksum, 1 hash sort, 2 match table (levels 4-9), 3 parse (the segmented multi-wave
+ * kernel at levels 4-9, the greedy kernel at levels 1-3), 4 parse of short buffers (wave-per-buffer
+ * kernels, levels 4-9), 5 huffman plan, 6 layout, 7 bit emit, 8 whole pass.  A plan that had to be
  * cut into sub-batches (zsc_hip_deflate_plan_sub_batches) launches every kernel once per
  * sub-batch; the times are sums over them.  Read after zsc_hip_deflate_plan_results(). */
-#define ZSC_HIP_NKERNELS 8
+#define ZSC_HIP_NKERNELS 9
 void zsc_hip_deflate_plan_profile(zsc_hip_deflate_plan *plan, I32 enable);
 ZlibReturn zsc_hip_deflate_plan_times(zsc_hip_deflate_plan *plan, float *ms_out);
 

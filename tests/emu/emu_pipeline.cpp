@@ -35,11 +35,7 @@ static inline void sg_count(int what, unsigned n)
 }
 #define SG_COUNT(what, n) sg_count(what, n)
 #include "../../zsc_amd/csrc/lz_parse_seg.h"
-/* lane-parallel parser: [1] candidates, [2] passers, [3] compare steps, [4] rounds, [5] advance blocks,
- * [6] walk blocks, [7] compare blocks, [8] heavy searches, [9]/[10]/[11] lanes active in those blocks */
-extern "C" { unsigned long long g_sl_cnt[16]; unsigned long long g_sl_hist[65]; unsigned g_sl_lane[1024], g_sl_call[1024], g_sl_modes[1024][8]; unsigned long long g_sl_bal[8]; unsigned long long g_sl_slow[8], g_sl_all[8], g_sl_bulk[8]; }
-#define SL_COUNT(what, n) (g_sl_cnt[what] += (n), (what) == 10 ? g_sl_hist[(n)]++ : 0ull)
-#include "../../zsc_amd/csrc/lz_parse_lane.h"
+#include "../../zsc_amd/csrc/match_table.h"
 #include "../../zsc_amd/csrc/lz_parse_simple.h"
 #include "../../zsc_amd/csrc/huff_plan.h"
 #include "../../zsc_amd/csrc/bit_emit.h"
@@ -76,8 +72,7 @@ struct EmuChains {
     std::vector<uint32_t> sorted, tmp;
     std::vector<uint16_t> rank, dir, hib;
     std::vector<uint32_t> cnt;
-    std::vector<uint16_t> sorted16;
-    std::vector<uint64_t> meta;
+    std::vector<uint32_t> r2, rl; /* the match table, when built */
 };
 
 static void build_chains(EmuChains &c, const uint8_t *src, uint32_t n)
@@ -92,8 +87,6 @@ static void build_chains(EmuChains &c, const uint8_t *src, uint32_t n)
     c.dir.assign((size_t)c.ntiles * ZD_DIR_STRIDE, 0xdead);
     c.hib.assign((size_t)n + 64, 0xdead);
     c.cnt.assign((size_t)n + 64, 0xdeaddead);
-    c.sorted16.assign((size_t)c.ntiles * ZD_TILE, 0xdead);
-    c.meta.assign((size_t)n + 64, 0xdeaddeaddeaddeadull);
     uint32_t owners = n >= 3 ? n - 2 : 0; /* positions 0..n-3 own a 3-byte string */
     for (uint32_t t = 0; t < c.ntiles; t++) {
         HsTile tile;
@@ -108,8 +101,6 @@ static void build_chains(EmuChains &c, const uint8_t *src, uint32_t n)
         tile.dir_prev = nullptr;
         tile.hib = nullptr;
         tile.cnt = nullptr;
-        tile.sorted16 = c.sorted16.data() + (size_t)t * ZD_TILE;
-        tile.meta = nullptr;
         HsLds lds;
         for (int ph = 0; ph < HS_PHASES; ph++)
             for (int w = 0; w < HS_WAVES; w++)
@@ -127,15 +118,70 @@ static void build_chains(EmuChains &c, const uint8_t *src, uint32_t n)
         tile.dir_prev = t ? c.dir.data() + (size_t)(t - 1) * ZD_DIR_STRIDE : nullptr;
         tile.hib = c.hib.data();
         tile.cnt = c.cnt.data();
-        tile.meta = c.meta.data();
         for (int w = 0; w < HS_WAVES; w++)
             hs_link_prev(tile, w);
     }
 }
 
+/* kernel 1c (match_table.h), as k_match_table runs it: only with the default window and hash size,
+ * levels 4-9, a match-finding strategy; switched with emu_set_table */
+static int g_use_table = 1;
+static uint32_t g_mt_cap = MT_CAP;
+extern "C" void emu_set_table_cap(uint32_t cap) { g_mt_cap = cap; }
+extern "C" void emu_set_table(int on) { g_use_table = on; }
+extern "C" { unsigned long long g_mt_cnt[4]; } /* [0] r2 entries, [1] incomplete ones, [2] rl entries searched, [3] incomplete ones */
+static void build_table(EmuChains &c, int level, int strategy)
+{
+    c.r2.clear();
+    c.rl.clear();
+    const ZdLevel cfg = level_cfg(level);
+    if (!g_use_table || !cfg.slow || cfg.wsize != ZD_TILE || cfg.hbits != 15u || strategy == 2 || strategy == 3)
+        return;
+    c.r2.assign((size_t)c.n + 64, 0xdeadbeefu);
+    c.rl.assign((size_t)c.n + 64, 0xdeadbeefu);
+    MtLds *lds = (MtLds *)malloc(sizeof(MtLds));
+    for (uint32_t t = 0; t < c.ntiles && t * ZD_TILE < c.n; t++) {
+        memset(lds, 0x3C, sizeof(MtLds));
+        MtJob job;
+        job.in = c.in.data();
+        job.n = c.n;
+        job.start = t * ZD_TILE;
+        job.sorted = c.sorted.data();
+        job.rank = c.rank.data();
+        job.hib = c.hib.data();
+        job.cnt = c.cnt.data();
+        job.r2 = c.r2.data();
+        job.rl = c.rl.data();
+        job.cfg = cfg;
+        job.strategy = (uint32_t)strategy;
+        job.cap = g_mt_cap;
+        for (int w = 0; w < MT_WAVES; w++)
+            mt_phase_load(job, lds, w);
+        const uint32_t base0 = sg_base(job.cfg, job.start, job.n);
+        const uint32_t left = job.n - job.start;
+        const uint32_t nchunk = ((left < ZD_TILE ? left : ZD_TILE) + MT_CHUNK - 1u) / MT_CHUNK;
+        for (uint32_t ch = 0; ch < nchunk; ch++) {
+            for (int w = 0; w < MT_WAVES; w++)
+                mt_phase_stage(job, lds, w, ch);
+            for (int w = 0; w < MT_WAVES; w++)
+                mt_phase_search(job, lds, w, ch, 0u, base0);
+            for (int w = 0; w < MT_WAVES; w++)
+                mt_phase_search(job, lds, w, ch, 1u, base0);
+        }
+    }
+    free(lds);
+    for (uint32_t p = 0; p < c.n; p++) {
+        g_mt_cnt[0]++;
+        g_mt_cnt[1] += (c.r2[p] & MT_INCOMPLETE) != 0;
+        if (p && !(c.r2[p - 1] & MT_INCOMPLETE) && MT_LEN(c.r2[p - 1]) >= 3 && MT_LEN(c.r2[p - 1]) < cfg.lazy) {
+            g_mt_cnt[2]++;
+            g_mt_cnt[3] += (c.rl[p] & MT_INCOMPLETE) != 0;
+        }
+    }
+}
+
 int g_seg_mode = 0; /* 0: runtime's choice, 1: force wave-per-buffer, 2: segmented, segments handed out last first,
-                       3: segmented, first first (a parser never finds its successors' traces),
-                       4: lane per segment where the configuration allows it */
+                       3: segmented, first first (a parser never finds its successors' traces) */
 extern "C" void emu_set_seg_mode(int m) { g_seg_mode = m; }
 
 static bool g_job_seg_ok = true; /* sections: may the segmented parser take the run with its joints? */
@@ -179,99 +225,8 @@ static void run_parse_seg(const LzJob &job0, int order)
     free(lds);
 }
 
-/* the lane-per-segment parser, its waves taking turns round by round (on the GPU they run at
- * the same time; a lane may have to wait for a lane of another wave) */
-static void run_parse_lane(const LzJob &job)
-{
-    SlLds *lds = (SlLds *)malloc(sizeof(SlLds));
-    memset(lds, 0x6B, sizeof(SlLds));
-    std::vector<uint32_t> tok((size_t)SL_SCRATCH_TOK, 0xDDDDDDDD);
-    std::vector<uint16_t> sidx((size_t)SL_SCRATCH_SIDX, 0xDDDD);
-    std::vector<uint32_t> xat((size_t)SL_SCRATCH_XAT, 0xDDDDDDDD);
-    SlScratch scr = {tok.data(), sidx.data(), xat.data()};
-    std::vector<SlWave> ws(SL_W);
-    for (int w = 0; w < SL_W; w++)
-        sl_init(lds, w);
-    uint32_t steps = 0;
-    while (!lds->finished) {
-        if (++steps > job.n / SL_G + 4) {
-            fprintf(stderr, "emu: lane parser stuck\n");
-            abort();
-        }
-        for (int w = 0; w < SL_W; w++)
-            sl_phase_load(job, lds, w);
-        for (int w = 0; w < SL_W; w++)
-            sl_phase_commit(job, lds, w);
-        for (int w = 0; w < SL_W; w++)
-            sl_parse_start(job, lds, w, ws[w]);
-        bool done[SL_W] = {};
-        for (uint64_t guard = 0;; guard++) {
-            bool all = true;
-            for (int w = SL_W - 1; w >= 0; w--) {
-                if (!done[w])
-                    done[w] = sl_parse_round(job, lds, scr, w, ws[w]) != 0;
-                all = all && done[w];
-            }
-            if (all)
-                break;
-            if (guard > 100000000ull) {
-                fprintf(stderr, "emu: lane parser round loop stuck\n");
-                abort();
-            }
-        }
-        {
-            unsigned long long sum = 0, mx = 0, mxc = 0, sumc = 0, g_wave_sum_max = 0;
-            for (unsigned w = 0; w < SL_W; w++) {
-                unsigned long long m = 0;
-                for (unsigned i = 0; i < 64; i++)
-                    m = g_sl_lane[w * 64 + i] > m ? g_sl_lane[w * 64 + i] : m;
-                g_wave_sum_max += m * 64;
-            }
-            {
-                unsigned worst = 0;
-                for (unsigned i = 0; i < SL_NS; i++)
-                    if (g_sl_lane[i] > g_sl_lane[worst]) worst = i;
-                for (int k = 0; k < 8; k++) {
-                    g_sl_slow[k] += g_sl_modes[worst][k];
-                    for (unsigned i = 0; i < SL_NS; i++) { g_sl_all[k] += g_sl_modes[i][k]; }
-                }
-                memset(g_sl_modes, 0, sizeof g_sl_modes);
-            }
-            for (unsigned i = 0; i < SL_NS; i++) {
-                sum += g_sl_lane[i];
-                mx = g_sl_lane[i] > mx ? g_sl_lane[i] : mx;
-                unsigned c = g_sl_lane[i] - (g_sl_call[i] > 256 ? g_sl_call[i] - 256 : 0); /* longest call capped at 256 */
-                sumc += c;
-                mxc = c > mxc ? c : mxc;
-                g_sl_lane[i] = g_sl_call[i] = 0;
-            }
-            g_sl_bal[0] += sum; g_sl_bal[1] += mx * SL_NS; g_sl_bal[2] += sumc; g_sl_bal[3] += mxc * SL_NS;
-            g_sl_bal[4] += g_wave_sum_max; /* sum over waves of (max lane of the wave) * 64 */
-        }
-        for (int w = 0; w < SL_W; w++)
-            sl_resolve_links(job, lds, scr, w);
-        for (int w = 0; w < SL_W; w++)
-            sl_resolve_chain(job, lds, w);
-        for (int w = 0; w < SL_W; w++)
-            sl_resolve_copy(job, lds, scr, w);
-        for (int w = 0; w < SL_W; w++)
-            sl_resolve_finish(job, lds, scr, w);
-    }
-    free(lds);
-}
-
-static bool lane_ok(const LzJob &job)
-{
-    return job.cfg.slow && job.nsched == 0 && !job.more && job.cfg.wsize == ZD_TILE && job.cfg.hbits == 15u &&
-           job.cfg.sym_cap == ZD_SYM_CAP && job.strategy != 2u && job.strategy != 3u;
-}
-
 static void run_parse(const LzJob &job)
 {
-    if (g_seg_mode == 4 && lane_ok(job)) {
-        run_parse_lane(job);
-        return;
-    }
     if (job.strategy == 2u || job.strategy == 3u) { /* Z_HUFFMAN_ONLY, Z_RLE */
         SpLds *lds = (SpLds *)malloc(sizeof(SpLds));
         memset(lds, 0x5D, sizeof(SpLds));
@@ -342,6 +297,7 @@ extern "C" int emu_parse(const uint8_t *src, uint32_t n, int level, int strategy
         return -2;
     EmuChains c;
     build_chains(c, src, n);
+    build_table(c, level, strategy);
     LzJob job;
     ZdParseOut out = {0, 0};
     job.in = c.in.data();
@@ -350,8 +306,8 @@ extern "C" int emu_parse(const uint8_t *src, uint32_t n, int level, int strategy
     job.rank = c.rank.data();
     job.hib = c.hib.data();
     job.cnt = c.cnt.data();
-    job.sorted16 = c.sorted16.data();
-    job.meta = c.meta.data();
+    job.r2 = c.r2.empty() ? nullptr : c.r2.data();
+    job.rl = c.rl.empty() ? nullptr : c.rl.data();
     job.syms = syms;
     job.blocks = blocks;
     job.out = &out;
@@ -391,6 +347,7 @@ extern "C" int emu_compress(const uint8_t *src, uint32_t n, int level, int wrap,
         return -2;
     EmuChains c;
     build_chains(c, src, n);
+    build_table(c, level, strategy);
     std::vector<uint32_t> syms((size_t)n + 64);
     uint32_t max_blocks = n / ((1u << (g_mem_level + 6)) - 1u) + 2;
     std::vector<ZdBlockRec> recs(max_blocks);
@@ -403,8 +360,8 @@ extern "C" int emu_compress(const uint8_t *src, uint32_t n, int level, int wrap,
     job.rank = c.rank.data();
     job.hib = c.hib.data();
     job.cnt = c.cnt.data();
-    job.sorted16 = c.sorted16.data();
-    job.meta = c.meta.data();
+    job.r2 = c.r2.empty() ? nullptr : c.r2.data();
+    job.rl = c.rl.empty() ? nullptr : c.rl.data();
     job.syms = syms.data();
     job.blocks = recs.data();
     job.out = &po;
@@ -460,7 +417,7 @@ extern "C" int emu_uncompress(const uint8_t *src, uint32_t n, int window_bits, u
     memset(lds, 0x3C, sizeof(InfLds));
     static uint32_t crc_table[1][256];
     lds->cktab = crc_table;
-    InfResult res;
+    InfResult res = {};
     inflate_with_resync(job, lds, &res);
     free(lds);
     *out_len = res.out_len;
@@ -499,10 +456,10 @@ struct EmuSecRunner {
             job.rank = c.rank.data();
             job.hib = c.hib.data();
             job.cnt = c.cnt.data();
-            job.sorted16 = c.sorted16.data();
-            job.meta = c.meta.data();
-    job.sorted16 = c.sorted16.data();
-    job.meta = c.meta.data();
+            if (r.sched.empty())
+                build_table(c, level, strategy);
+            job.r2 = c.r2.empty() ? nullptr : c.r2.data();
+            job.rl = c.rl.empty() ? nullptr : c.rl.data();
             job.syms = syms.data();
             job.blocks = recs.data();
             job.out = &po;

@@ -26,6 +26,6 @@ for i, (name, size, kind) in enumerate(list(corpus.CANTERBURY_LIKE) + extra):
     t = plan.kernel_times_ms()
     assert all(s == 0 for s in st)
     rows.append((name, size, lens[0], t))
-    print(f"{name:14s} n={size:8d} out={lens[0]:8d} parse={t['parse']:9.2f} ms sort={t['hash_sort']:7.2f} plan={t['huff_plan']:6.2f} emit={t['emit']:6.2f} "
+    print(f"{name:14s} n={size:8d} out={lens[0]:8d} table={t['match_table']:7.2f} parse={t['parse']:9.2f} ms sort={t['hash_sort']:7.2f} plan={t['huff_plan']:6.2f} emit={t['emit']:6.2f} "
           f"-> {size*copies/t['total']/1e6:8.2f} GB/s total, per-wave parse {size/t['parse']/1e3:7.3f} MB/s", flush=True)
     plan.close(); del d_in, d_out

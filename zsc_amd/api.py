@@ -19,8 +19,8 @@ Z_OK, Z_STREAM_END, Z_NEED_DICT = 0, 1, 2
 Z_ERRNO, Z_STREAM_ERROR, Z_DATA_ERROR, Z_MEM_ERROR, Z_BUF_ERROR, Z_VERSION_ERROR = -1, -2, -3, -4, -5, -6
 Z_DEFAULT_STRATEGY, Z_FILTERED, Z_HUFFMAN_ONLY, Z_RLE, Z_FIXED = 0, 1, 2, 3, 4
 GZIP_CODE, DEF_WBITS, DEF_MEM_LEVEL = 16, 15, 8
-NKERNELS = 8
-KERNEL_NAMES = ("checksum", "hash_sort", "parse", "parse_short", "huff_plan", "layout", "emit", "total")
+NKERNELS = 9
+KERNEL_NAMES = ("checksum", "hash_sort", "match_table", "parse", "parse_short", "huff_plan", "layout", "emit", "total")
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 lib_path = os.environ.get("ZSC_HIP_LIB") or os.path.join(_HERE, "libzsc_hip.so")  # env: experiments only

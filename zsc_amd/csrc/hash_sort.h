@@ -53,7 +53,6 @@ typedef struct {
     uint32_t start;     /* absolute position of the tile's first byte */
     uint32_t m;         /* positions of this tile that own a 3-byte string (pos <= n-3) */
     uint32_t *sorted;   /* TILE entries */
-    uint16_t *sorted16; /* the same order, positions only (what the lane-per-segment parser reads); may be null */
     uint32_t *tmp;      /* TILE entries */
     uint16_t *rank;     /* per position of the buffer */
     uint16_t *dir;      /* DIR_STRIDE entries: first sorted index of every bucket */
@@ -61,7 +60,6 @@ typedef struct {
     uint16_t *hib;      /* per position of the buffer: last sorted index of its bucket in the previous tile */
     uint32_t *cnt;      /* per position of the buffer: earlier members of its bucket in its own tile (low
                            half) and members of the bucket in the previous tile (high half) */
-    uint64_t *meta;     /* per position of the buffer: rank | hib << 16 | cnt << 32 in one record; may be null */
 } HsTile;
 
 /* UPDATE_HASH over three bytes, reference src/deflate.c:174-175 */
@@ -152,8 +150,6 @@ DEV void hs_scatter(const HsTile &t, HsLds *lds, int w, int pass)
                     LDS_ADD_U32(&lds->cnt1[(LV(ent) >> 24) * HS_WAVES + LV(dst) / slice], 1u);
                 } else {
                     t.sorted[LV(dst)] = LV(ent);
-                    if (t.sorted16)
-                        t.sorted16[LV(dst)] = (uint16_t)(LV(ent) & ZD_TILE_MASK);
                     t.rank[t.start + (LV(ent) & ZD_TILE_MASK)] = (uint16_t)LV(dst);
                 }
             }
@@ -285,8 +281,6 @@ DEV void hs_link_prev(const HsTile &t, int w)
                         c |= (LVA(pend, k) - LVA(plo, k)) << 16;
                     }
                     t.cnt[t.start + i] = c;
-                    if (t.meta)
-                        t.meta[t.start + i] = (uint64_t)(LVA(rk, k) | (hb << 16)) | ((uint64_t)c << 32);
                 }
             }
         }

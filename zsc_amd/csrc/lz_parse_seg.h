@@ -53,14 +53,6 @@
 #ifndef SG_SPAN
 #define SG_SPAN 8192u               /* positions per super-step */
 #endif
-/* SG_ENT16=1: chain entries read as 16-bit positions (sorted16) instead of position | hash << 16
- * (sorted) -- the parser never looks at the hash half, and a 64-candidate load is one 128-byte
- * line.  Measured (x4096, level 6): the parse 2 847 -> 2 834 ms, but the sort's third scattered
- * store costs 28 ms (233 -> 262 ms), and the sort itself needs the hash half (second pass,
- * directory), so the 32-bit entries stay. */
-#ifndef SG_ENT16
-#define SG_ENT16 0
-#endif
 #ifndef SG_MIN_WAVES
 #define SG_MIN_WAVES 6 /* waves per SIMD the register allocation aims at (three workgroups per CU) */
 #endif
@@ -503,6 +495,93 @@ DEV void sg_phase_begin(const LzJob &job, SgLds *lds, int w)
         }                                                                                     \
     } while (0)
 
+/* ---- hops: the parse as a walk over the match table ---------------------------------------
+ *
+ * With the table (match_table.h) a parser that stands at x with no match pending does not have
+ * to search: r2[x] says what longest_match finds there, rl[x+1] whether the lazy evaluation at
+ * x+1 finds something longer, and so on -- everything deflate_slow does until it next stands at
+ * a position with no match pending follows from a few table entries.  Each lane works that out
+ * for one of 64 consecutive positions at once (a HOP: the literals and the match that are
+ * emitted, the position the parse stands at next); the wave then only follows the hops.  A
+ * position whose entries are not all known (MT_INCOMPLETE, or a fourth lazy step) has no hop
+ * and goes through the search below as before. */
+#define SGH_VALID 0x80000000u
+#define SGH_MATCH 0x40000000u /* literals (bits 28-29 say how many), then the match in bits 0-23 (MT_LEN / MT_DIST) */
+
+/* rl of position X for the length KEY, given A = r2[X]: r2 answers itself where it may (MT_RLOK) */
+#define SG_RL(X, A, KEY) (((A)&MT_RLOK) ? (MT_LEN(A) > (KEY) ? (A) : MT_NONE) : job.rl[X])
+
+/* hops of positions X0 .. X0+GRP-1: LV(hop), and the four input bytes at each position LV(hby) */
+#define SG_HOP_LOAD(X0)                                                                       \
+    FOR_GLANES                                                                                 \
+    {                                                                                         \
+        const uint32_t x = (X0) + (uint32_t)GLANE;                                             \
+        uint32_t h = 0, by = 0;                                                               \
+        if ((uint64_t)x + 4u <= job.n) {                                                      \
+            const uint32_t a0 = job.r2[x];                                                    \
+            by = ld_u32(job.in + x);                                                          \
+            if (!(a0 & MT_INCOMPLETE)) {                                                      \
+                const uint32_t l1 = MT_LEN(a0);                                               \
+                if (l1 == 2u) {                                                               \
+                    h = SGH_VALID;                                                            \
+                } else {                                                                      \
+                    uint32_t fin = a0, nlit = 0;                                              \
+                    int good = 1;                                                             \
+                    if (l1 < job.cfg.lazy) {                                                  \
+                        const uint32_t a1 = job.r2[x + 1u];                                   \
+                        const uint32_t b1 = SG_RL(x + 1u, a1, l1);                            \
+                        if (b1 & MT_INCOMPLETE) {                                             \
+                            good = 0;                                                         \
+                        } else if (MT_LEN(b1) > l1) {                                         \
+                            const uint32_t l2 = MT_LEN(b1);                                   \
+                            fin = b1;                                                         \
+                            nlit = 1;                                                         \
+                            if (l2 < job.cfg.lazy) {                                          \
+                                /* rl[x+2] answers for the length in r2[x+1]: is that l2? */   \
+                                const uint32_t a2 = job.r2[x + 2u];                           \
+                                const uint32_t b2 = SG_RL(x + 2u, a2, l2);                    \
+                                if (((a1 | b2) & MT_INCOMPLETE) || MT_LEN(a1) != l2) {        \
+                                    good = 0;                                                 \
+                                } else if (MT_LEN(b2) > l2) {                                 \
+                                    const uint32_t l3 = MT_LEN(b2);                           \
+                                    fin = b2;                                                 \
+                                    nlit = 2;                                                 \
+                                    if (l3 < job.cfg.lazy) {                                  \
+                                        const uint32_t a3 = job.r2[x + 3u];                   \
+                                        const uint32_t b3 = SG_RL(x + 3u, a3, l3);            \
+                                        if (((a2 | b3) & MT_INCOMPLETE) || MT_LEN(a2) != l3 || MT_LEN(b3) > l3) \
+                                            good = 0;                                         \
+                                    }                                                         \
+                                }                                                             \
+                            }                                                                 \
+                        }                                                                     \
+                    }                                                                         \
+                    if (good)                                                                 \
+                        h = SGH_VALID | SGH_MATCH | (nlit << 28) | (fin & 0xffffffu);         \
+                }                                                                             \
+            }                                                                                 \
+        }                                                                                     \
+        LV(hop) = h;                                                                          \
+        LV(hby) = by;                                                                         \
+    }
+
+/* one token to the segment's token area (through a register, 64 at a time) */
+#define SG_EMIT(SYM)                                                                          \
+    do {                                                                                      \
+        const uint32_t _sym = (SYM);                                                          \
+        FOR_GLANES                                                                             \
+        {                                                                                     \
+            if ((uint32_t)GLANE == nstaged)                                                    \
+                LV(stg) = _sym;                                                               \
+        }                                                                                     \
+        nstaged++;                                                                            \
+        ntok++;                                                                               \
+        if (nstaged == GRP) {                                                                 \
+            FOR_GLANES { tok[ntok - GRP + (uint32_t)GLANE] = LV(stg); }                        \
+            nstaged = 0;                                                                      \
+        }                                                                                     \
+    } while (0)
+
 /* parse from (p, cur_len, cur_at, pending) -- a state of the serial parse, or the fresh
  * state at the start of segment s -- until the parse can be handed to a later segment's
  * tokens, gives up, or leaves the super-step */
@@ -545,7 +624,10 @@ DEV void sg_parse_segment(const LzJob &job, SgLds *lds, const SgScratch &scr, ui
     LANEVAR(uint32_t, pv);
     LANEVAR(uint32_t, stg);
     LANEVAR(uint32_t, sdx);
-    FOR_GLANES { LV(mrk) = LV(mcn) = LV(pv) = LV(stg) = LV(sdx) = 0; }
+    LANEVAR(uint32_t, hop); /* hops of the positions from hop_at on, and the input bytes there */
+    LANEVAR(uint32_t, hby);
+    FOR_GLANES { LV(mrk) = LV(mcn) = LV(pv) = LV(stg) = LV(sdx) = LV(hop) = LV(hby) = 0; }
+    uint32_t hop_at = p + 4096u; /* (out of range, as the other caches) */
     /* the two caches start out of range of p, so that their one range test fails */
     uint32_t mt_at = p + 4096u, pv_at = 0xffffffffu;
     uint32_t lit = 0;                      /* the byte at p-1 */
@@ -616,6 +698,32 @@ DEV void sg_parse_segment(const LzJob &job, SgLds *lds, const SgScratch &scr, ui
             }
         }
 
+        if (job.r2 != nullptr && fresh) {
+            if (p - hop_at >= GRP) {
+                hop_at = p;
+                SG_HOP_LOAD(p);
+            }
+            const uint32_t h = GREADLANE(hop, p - hop_at);
+            if (h & SGH_VALID) {
+                const uint32_t by = GREADLANE(hby, p - hop_at);
+                SG_COUNT(7, 1);
+                if (pending)
+                    SG_EMIT(lit);
+                if (h & SGH_MATCH) {
+                    const uint32_t nlit = (h >> 28) & 3u;
+                    for (uint32_t i = 0; i < nlit; i++)
+                        SG_EMIT((by >> (8u * i)) & 0xffu);
+                    SG_EMIT((MT_DIST(h) << 16) | (MT_LEN(h) - 3u));
+                    p += nlit + MT_LEN(h);
+                    pending = 0;
+                } else {
+                    lit = by & 0xffu;
+                    pending = 1;
+                    p++;
+                }
+                continue;
+            }
+        }
         uint32_t s0123;
         SG_PEEK32(p, s0123);
         const uint32_t prev_len = cur_len, prev_at = cur_at;
@@ -637,11 +745,7 @@ DEV void sg_parse_segment(const LzJob &job, SgLds *lds, const SgScratch &scr, ui
                 SG_COUNT(5, 1);
                 const int32_t hiA = (int32_t)(rh & 0xffffu) - 1, hiB = (int32_t)(rh >> 16);
                 const uint32_t tileA = p & ~ZD_TILE_MASK;
-#if SG_ENT16
-                const uint16_t *runA = job.sorted16 + (uint64_t)(p >> 15) * ZD_TILE;
-#else
                 const uint32_t *runA = job.sorted + (uint64_t)(p >> 15) * ZD_TILE;
-#endif
                 const uint32_t floor_pos = p - st.base > job.cfg.max_dist ? p - job.cfg.max_dist : st.base;
                 const uint32_t cap = look < 258u ? look : 258u;
                 const uint32_t nice = job.cfg.nice < look ? job.cfg.nice : look;
@@ -754,19 +858,8 @@ DEV void sg_parse_segment(const LzJob &job, SgLds *lds, const SgScratch &scr, ui
             p++;
         }
         lit = s0123 & 0xffu; /* the byte a literal emitted by the next iteration stands for */
-        if (emit) {
-            FOR_GLANES
-            {
-                if ((uint32_t)GLANE == nstaged)
-                    LV(stg) = sym;
-            }
-            nstaged++;
-            ntok++;
-            if (nstaged == GRP) {
-                FOR_GLANES { tok[ntok - GRP + (uint32_t)GLANE] = LV(stg); }
-                nstaged = 0;
-            }
-        }
+        if (emit)
+            SG_EMIT(sym);
     }
     FOR_GLANES
     {

@@ -97,6 +97,17 @@ typedef struct {
     uint32_t pad;
 } ZdSched;
 
+/* one entry of the match table (match_table.h): what longest_match returns at a position for one
+ * value of prev_length, after the TOO_FAR / Z_FILTERED rule -- match_length in bits 0-8 (2 = no
+ * match, or none longer than prev_length), distance - 1 in bits 9-23, flags in bits 30-31 */
+#define MT_INCOMPLETE 0x80000000u /* not known: the parser searches itself */
+#define MT_RLOK 0x40000000u       /* (r2 only) the entry also answers for any longer prev_length: the same
+                                     match if it is longer than prev_length, none otherwise */
+#define MT_LEN(e) ((e)&0x1ffu)
+#define MT_DIST(e) ((((e) >> 9) & 0x7fffu) + 1u)
+#define MT_PACK(len, dist) ((uint32_t)(len) | (((uint32_t)(dist)-1u) << 9))
+#define MT_NONE MT_PACK(2u, 1u)
+
 /* what the parser reports per buffer */
 typedef struct {
     uint32_t nsyms;

@@ -27,7 +27,7 @@
 #include "inflate.h"
 #include "lz_parse.h"
 #include "lz_parse_seg.h"
-#include "lz_parse_lane.h"
+#include "match_table.h"
 #include "lz_parse_simple.h"
 #include "sections.h"
 #include "zsc_dev.h"
@@ -149,7 +149,7 @@ __global__ __launch_bounds__(HS_WAVES * 64) void k_hash_sort(
     const uint8_t *__restrict__ in, const ZdBuf *__restrict__ bufs,
     const uint32_t *__restrict__ tile_owner, uint32_t *__restrict__ sorted,
     uint32_t *__restrict__ tmp, uint16_t *__restrict__ rank, uint16_t *__restrict__ dir,
-    uint16_t *__restrict__ sorted16, uint32_t ntiles)
+    uint32_t ntiles)
 {
     __shared__ HsLds lds;
     const uint32_t tile = blockIdx.x;
@@ -164,8 +164,6 @@ __global__ __launch_bounds__(HS_WAVES * 64) void k_hash_sort(
     const uint32_t owners = buf.in_len >= 3 ? buf.in_len - 2 : 0;
     job.m = owners > job.start ? min(owners - job.start, ZD_TILE) : 0u;
     job.sorted = sorted + (uint64_t)tile * ZD_TILE;
-    job.sorted16 = sorted16 ? sorted16 + (uint64_t)tile * ZD_TILE : nullptr;
-    job.meta = nullptr;
     job.tmp = tmp + (uint64_t)tile * ZD_TILE;
     job.rank = rank + buf.rank_off;
     job.dir = dir + (uint64_t)tile * ZD_DIR_STRIDE;
@@ -184,7 +182,7 @@ __global__ __launch_bounds__(HS_WAVES * 64) void k_link_prev(
     const uint8_t *__restrict__ in, const ZdBuf *__restrict__ bufs,
     const uint32_t *__restrict__ tile_owner, const uint16_t *__restrict__ dir,
     const uint16_t *__restrict__ rank, uint16_t *__restrict__ hib, uint32_t *__restrict__ cnt,
-    uint64_t *__restrict__ meta, uint32_t ntiles)
+    uint32_t ntiles)
 {
     const uint32_t tile = blockIdx.x;
     if (tile >= ntiles)
@@ -198,8 +196,6 @@ __global__ __launch_bounds__(HS_WAVES * 64) void k_link_prev(
     const uint32_t owners = buf.in_len >= 3 ? buf.in_len - 2 : 0;
     job.m = owners > job.start ? min(owners - job.start, ZD_TILE) : 0u;
     job.sorted = nullptr;
-    job.sorted16 = nullptr;
-    job.meta = meta ? meta + buf.rank_off : nullptr;
     job.tmp = nullptr;
     job.rank = const_cast<uint16_t *>(rank) + buf.rank_off;
     job.dir = const_cast<uint16_t *>(dir) + (uint64_t)tile * ZD_DIR_STRIDE;
@@ -207,6 +203,61 @@ __global__ __launch_bounds__(HS_WAVES * 64) void k_link_prev(
     job.hib = hib + buf.rank_off;
     job.cnt = cnt + buf.rank_off;
     hs_link_prev(job, (int)(threadIdx.x >> 6));
+}
+
+/* kernel 1c: one workgroup per tile: longest_match for every position of the tile, for the two
+ * values of prev_length the lazy parse can ask with (match_table.h) */
+#ifdef MT_EU
+#define MT_ATTR __attribute__((amdgpu_waves_per_eu(MT_EU, MT_EU)))
+#else
+#define MT_ATTR
+#endif
+__global__ __launch_bounds__(MT_WAVES * 64) MT_ATTR void k_match_table(
+    const uint8_t *__restrict__ in, const ZdBuf *__restrict__ bufs,
+    const uint32_t *__restrict__ tile_owner, const uint32_t *__restrict__ sorted,
+    const uint16_t *__restrict__ rank, const uint16_t *__restrict__ hib,
+    const uint32_t *__restrict__ cnt, uint32_t *__restrict__ r2, uint32_t *__restrict__ rl,
+    const ZdLevel cfg, uint32_t min_len, uint32_t cap, uint32_t ntiles)
+{
+    __shared__ MtLds lds;
+    const uint32_t tile = blockIdx.x;
+    if (tile >= ntiles)
+        return;
+    const ZdBuf buf = bufs[tile_owner[tile]];
+    /* only what the segmented parser takes without joints reads the table */
+    if (buf.in_len <= min_len || buf.sched_n != 0)
+        return;
+    MtJob job;
+    job.in = in + buf.in_off;
+    job.n = buf.in_len;
+    job.start = (tile - buf.tile0) * ZD_TILE;
+    job.sorted = sorted + (uint64_t)buf.tile0 * ZD_TILE;
+    job.rank = rank + buf.rank_off;
+    job.hib = hib + buf.rank_off;
+    job.cnt = cnt + buf.rank_off;
+    job.r2 = r2 + buf.rank_off;
+    job.rl = rl + buf.rank_off;
+    job.cfg = cfg;
+    job.cfg.wsize = ZD_TILE;
+    job.cfg.max_dist = ZD_MAX_DIST;
+    job.cfg.sym_cap = ZD_SYM_CAP;
+    job.cfg.hbits = 15u;
+    job.strategy = buf.strategy;
+    job.cap = cap;
+    const int w = (int)(threadIdx.x >> 6);
+    mt_phase_load(job, &lds, w);
+    __syncthreads();
+    const uint32_t base0 = sg_base(job.cfg, job.start, job.n);
+    const uint32_t left = job.n - job.start;
+    const uint32_t nchunk = ((left < ZD_TILE ? left : ZD_TILE) + MT_CHUNK - 1u) / MT_CHUNK;
+    for (uint32_t c = 0; c < nchunk; c++) {
+        mt_phase_stage(job, &lds, w, c);
+        __syncthreads();
+        mt_phase_search(job, &lds, w, c, 0u, base0);
+        __syncthreads();
+        mt_phase_search(job, &lds, w, c, 1u, base0);
+        __syncthreads();
+    }
 }
 
 /* kernel 2: one wavefront per buffer, longest buffers first.  L picks the LDS ring
@@ -238,8 +289,7 @@ __global__ __launch_bounds__(64) void k_parse(const uint8_t *__restrict__ in,
     job.rank = rank + buf.rank_off;
     job.hib = hib + buf.rank_off;
     job.cnt = nullptr;
-    job.sorted16 = nullptr;
-    job.meta = nullptr;
+    job.r2 = job.rl = nullptr;
     job.syms = syms + buf.sym_off;
     job.blocks = recs + buf.blk0;
     job.out = pout + b;
@@ -262,7 +312,8 @@ __global__ __launch_bounds__(SG_W * 64, SG_MIN_WAVES) void k_parse_seg(const uin
                                                          const uint16_t *__restrict__ rank,
                                                          const uint16_t *__restrict__ hib,
                                                          const uint32_t *__restrict__ cnt,
-                                                         const uint16_t *__restrict__ sorted16,
+                                                         const uint32_t *__restrict__ r2,
+                                                         const uint32_t *__restrict__ rl,
                                                          uint32_t *__restrict__ syms,
                                                          ZdBlockRec *__restrict__ recs,
                                                          ZdParseOut *__restrict__ pout,
@@ -285,8 +336,9 @@ __global__ __launch_bounds__(SG_W * 64, SG_MIN_WAVES) void k_parse_seg(const uin
     job.rank = rank + buf.rank_off;
     job.hib = hib + buf.rank_off;
     job.cnt = cnt + buf.rank_off;
-    job.sorted16 = sorted16 ? sorted16 + (uint64_t)buf.tile0 * ZD_TILE : nullptr;
-    job.meta = nullptr;
+    /* the match table covers plain buffers (match_table.h); a run with joints is searched as before */
+    job.r2 = r2 && buf.sched_n == 0 ? r2 + buf.rank_off : nullptr;
+    job.rl = rl && buf.sched_n == 0 ? rl + buf.rank_off : nullptr;
     job.syms = syms + buf.sym_off;
     job.blocks = recs + buf.blk0;
     job.out = pout + b;
@@ -357,101 +409,6 @@ __global__ __launch_bounds__(SG_W * 64, SG_MIN_WAVES) void k_parse_seg(const uin
     }
 }
 
-/* kernel 2 for levels 4-9 at window_bits 15 / mem_level 8: every lane of the workgroup parses
- * its own segment of the buffer (lz_parse_lane.h).  A workgroup takes buffers off a counter
- * until none are left. */
-__global__ __launch_bounds__(SL_W * 64, (2 * SL_W + 3) / 4) void k_parse_lane(
-    const uint8_t *__restrict__ in, const ZdBuf *__restrict__ bufs,
-    const uint32_t *__restrict__ order, const uint32_t *__restrict__ sorted,
-    const uint16_t *__restrict__ sorted16, const uint64_t *__restrict__ meta,
-    uint32_t *__restrict__ syms, ZdBlockRec *__restrict__ recs,
-    ZdParseOut *__restrict__ pout, uint32_t *__restrict__ lane_tok,
-    uint16_t *__restrict__ lane_sidx, uint32_t *__restrict__ lane_xat,
-    uint32_t *__restrict__ next_buf, const ZdLevel cfg, uint32_t first, uint32_t nbuf)
-{
-    __shared__ SlLds lds;
-    __shared__ uint32_t cur_buf;
-    SlScratch scr;
-    scr.tok = lane_tok + (uint64_t)blockIdx.x * SL_SCRATCH_TOK;
-    scr.sidx = lane_sidx + (uint64_t)blockIdx.x * SL_SCRATCH_SIDX;
-    scr.xat = lane_xat + (uint64_t)blockIdx.x * SL_SCRATCH_XAT;
-    const int w = (int)(threadIdx.x >> 6);
-    for (;;) {
-        __syncthreads(); /* everybody is done with the previous buffer (and has read cur_buf) */
-        if (threadIdx.x == 0)
-            cur_buf = atomicAdd(next_buf, 1u);
-        __syncthreads();
-        const uint32_t k = cur_buf;
-        if (k >= nbuf)
-            return;
-        const uint32_t b = order[first + k];
-        const ZdBuf buf = bufs[b];
-        LzJob job;
-        job.in = in + buf.in_off;
-        job.n = buf.in_len;
-        job.ntot = buf.in_len;
-        job.sorted = sorted + (uint64_t)buf.tile0 * ZD_TILE;
-        job.sorted16 = sorted16 + (uint64_t)buf.tile0 * ZD_TILE;
-        job.meta = meta + buf.rank_off;
-        job.rank = nullptr;
-        job.hib = nullptr;
-        job.cnt = nullptr;
-        job.syms = syms + buf.sym_off;
-        job.blocks = recs + buf.blk0;
-        job.out = pout + b;
-        job.cfg = cfg;
-        job.cfg.wsize = ZD_TILE;
-        job.cfg.max_dist = ZD_MAX_DIST;
-        job.cfg.sym_cap = ZD_SYM_CAP;
-        job.cfg.hbits = 15u;
-        job.strategy = buf.strategy;
-        job.more = 0;
-        job.sched = nullptr;
-        job.nsched = 0;
-        job.n0 = buf.in_len;
-        sl_init(&lds, w);
-        __syncthreads();
-        /* bounded, so that a logic error can never hang the device: every super-step moves on
-         * by at least one segment */
-        const uint32_t max_steps = buf.in_len / SL_G + 4;
-        uint32_t steps = 0;
-        bool stuck = false;
-        while (!lds.finished) {
-            if (++steps > max_steps) {
-                stuck = true;
-                break;
-            }
-            sl_phase_load(job, &lds, w);
-            __syncthreads();
-            sl_phase_commit(job, &lds, w);
-            __syncthreads();
-            SlWave ws;
-            sl_parse_start(job, &lds, w, ws);
-            __syncthreads();
-            uint32_t rounds = 0;
-            while (!sl_parse_round(job, &lds, scr, w, ws)) {
-                /* a lane walks at most a window of candidates per position, compares 258 bytes
-                 * per candidate that passes, and there are SL_SPAN positions */
-                if (++rounds > 400000000u)
-                    break;
-            }
-            __syncthreads();
-            sl_resolve_links(job, &lds, scr, w);
-            __syncthreads();
-            sl_resolve_chain(job, &lds, w);
-            __syncthreads();
-            sl_resolve_copy(job, &lds, scr, w);
-            __syncthreads();
-            sl_resolve_finish(job, &lds, scr, w);
-            __syncthreads();
-        }
-        if (stuck && threadIdx.x == 0) {
-            job.out->nsyms = 0;
-            job.out->nblocks = 0xffffffffu; /* reported as Z_STREAM_ERROR by the layout kernel */
-        }
-    }
-}
-
 /* kernel 2 for Z_HUFFMAN_ONLY and Z_RLE: no chains, no window (lz_parse_simple.h) */
 __global__ __launch_bounds__(64) void k_parse_simple(const uint8_t *__restrict__ in,
                                                      const ZdBuf *__restrict__ bufs,
@@ -474,8 +431,7 @@ __global__ __launch_bounds__(64) void k_parse_simple(const uint8_t *__restrict__
     job.rank = nullptr;
     job.hib = nullptr;
     job.cnt = nullptr;
-    job.sorted16 = nullptr;
-    job.meta = nullptr;
+    job.r2 = job.rl = nullptr;
     job.syms = syms + buf.sym_off;
     job.blocks = recs + buf.blk0;
     job.out = pout + b;
@@ -519,8 +475,7 @@ __global__ __launch_bounds__(64) void k_parse_fast(const uint8_t *__restrict__ i
     job.rank = rank + buf.rank_off;
     job.hib = hib + buf.rank_off;
     job.cnt = nullptr;
-    job.sorted16 = nullptr;
-    job.meta = nullptr;
+    job.r2 = job.rl = nullptr;
     job.syms = syms + buf.sym_off;
     job.blocks = recs + buf.blk0;
     job.out = pout + b;
@@ -848,8 +803,7 @@ struct SubBatch {
     /* the length-sorted order (longest first) splits into ring-size classes:
      * [0,c36) full ring, [c36,c16) <= 18 432 B, [c16,c8) <= 10 240 B, [c8,count) <= 6 144 B */
     uint32_t c36 = 0, c16 = 0, c8 = 0;
-    uint32_t clane = 0; /* [0,clane) of the length-sorted order go to the lane-per-segment parser, */
-    uint32_t cseg = 0;  /* [clane,cseg) to the segmented parser */
+    uint32_t cseg = 0;  /* [0,cseg) of the length-sorted order go to the segmented parser */
 };
 
 } // namespace
@@ -863,10 +817,10 @@ struct zsc_hip_deflate_plan {
     /* scratch shared by all sub-batches (sized for the largest) */
     DevBuf d_sorted, d_tmp_syms, d_rank, d_hib, d_cnt, d_dir, d_recs, d_plans, d_pout;
     DevBuf d_seg_tok, d_seg_sidx; /* per long buffer: token staging of the segmented parser */
-    DevBuf d_lane_tok, d_lane_sidx, d_lane_xat, d_lane_ctr; /* per workgroup of the lane-per-segment parser */
-    DevBuf d_sorted16, d_meta; /* what that parser reads instead of sorted / rank / hib / cnt */
-    uint32_t lane_grid = 0;
-    bool use_lane = true;
+    DevBuf d_r2, d_rl; /* the match table (match_table.h): two entries per input position */
+    bool use_table = false;
+    uint32_t table_min = 0; /* buffers longer than this have a table (those the segmented parser takes) */
+    uint32_t table_cap = MT_CAP;
     DevBuf d_sched;               /* joints of runs of sections (sections.h) */
     bool use_seg = true;
     DevBuf d_res; /* one ZdResult per buffer of the whole plan */
@@ -1107,13 +1061,6 @@ static ZlibReturn plan_create(zsc_hip_deflate_plan **plan_out, U32 count, const 
     }
 
     pl->use_seg = getenv("ZSC_HIP_NO_SEG") == nullptr && kLevels[level].slow;
-    /* the lane-per-segment parser: levels 4-9 with the default window and block size; the
-     * match-finding strategies (default, filtered, fixed) share its parse */
-    pl->use_lane = getenv("ZSC_HIP_LANE") != nullptr && kLevels[level].slow && wbits == 15 &&
-                   mem_level == 8 && strategy != Z_HUFFMAN_ONLY && strategy != Z_RLE;
-    uint32_t lane_min = 18432u;
-    if (const char *e = getenv("ZSC_HIP_LANE_MIN"))
-        lane_min = (uint32_t)atoll(e);
     /* per-sub-batch descriptor arrays */
     for (SubBatch &sb : pl->subs) {
         std::vector<uint32_t> tile_owner(sb.ntiles), blk_owner(sb.nslots), order(sb.count);
@@ -1130,17 +1077,13 @@ static ZlibReturn plan_create(zsc_hip_deflate_plan **plan_out, U32 count, const 
          * parsing, 8 192: 2 853 + 13 ms, 3 072: 2 853 + 0 ms -- a workgroup per 4 KiB file still
          * beats a wave per file */
         static const uint32_t seg_min = getenv("ZSC_HIP_SEG_MIN") ? (uint32_t)atoi(getenv("ZSC_HIP_SEG_MIN")) : 3072u;
-        /* longest first; among the long ones, those the lane-per-segment parser takes come
-         * first, then those the segmented parser may take */
-        auto lane_able = [&](uint32_t k) {
-            const ZdBuf &b = pl->bufs[sb.first + k];
-            return pl->use_lane && b.in_len > lane_min && b.sched_n == 0 && !b.more;
-        };
+        pl->table_min = seg_min;
+        /* longest first; those the segmented parser may take come first */
         auto seg_able = [&](uint32_t k) {
             const ZdBuf &b = pl->bufs[sb.first + k];
             return pl->use_seg && b.in_len > seg_min && (b.sched_n == 0 || b.seg_ok);
         };
-        auto klass = [&](uint32_t k) { return lane_able(k) ? 0 : seg_able(k) ? 1 : 2; };
+        auto klass = [&](uint32_t k) { return seg_able(k) ? 1 : 2; };
         std::stable_sort(order.begin(), order.end(), [&](uint32_t a, uint32_t c) {
             const int ka = klass(a), kc = klass(c);
             if (ka != kc)
@@ -1151,9 +1094,6 @@ static ZlibReturn plan_create(zsc_hip_deflate_plan **plan_out, U32 count, const 
             const bool full_only = getenv("ZSC_HIP_FULL_RING") != nullptr;
             uint32_t k = 0;
             auto len_at = [&](uint32_t idx) { return pl->bufs[sb.first + order[idx]].in_len; };
-            while (k < sb.count && lane_able(order[k]))
-                k++;
-            sb.clane = k;
             while (k < sb.count && seg_able(order[k]))
                 k++;
             sb.cseg = k;
@@ -1199,28 +1139,9 @@ static ZlibReturn plan_create(zsc_hip_deflate_plan **plan_out, U32 count, const 
         }
         pl->scratch_bytes += pl->d_sched.bytes;
     }
-    uint64_t max_seg = 0, max_lane = 0;
-    for (const SubBatch &sb : pl->subs) {
-        max_seg = std::max<uint64_t>(max_seg, sb.cseg - sb.clane);
-        max_lane = std::max<uint64_t>(max_lane, sb.clane);
-    }
-    if (max_lane) {
-        /* as many workgroups as the device holds at once (two per CU), each with its own
-         * token staging; they take buffers off a counter */
-        uint32_t grid = 512;
-        if (const char *e = getenv("ZSC_HIP_LANE_GRID"))
-            grid = (uint32_t)std::max(1ll, atoll(e));
-        pl->lane_grid = (uint32_t)std::min<uint64_t>(max_lane, grid);
-        if (!pl->d_lane_tok.ensure((uint64_t)pl->lane_grid * SL_SCRATCH_TOK * 4ull) ||
-            !pl->d_lane_sidx.ensure((uint64_t)pl->lane_grid * SL_SCRATCH_SIDX * 2ull) ||
-            !pl->d_lane_xat.ensure((uint64_t)pl->lane_grid * SL_SCRATCH_XAT * 4ull) ||
-            !pl->d_lane_ctr.ensure(256)) {
-            zsc_hip_deflate_plan_destroy(pl);
-            return Z_MEM_ERROR;
-        }
-        pl->scratch_bytes += pl->d_lane_tok.bytes + pl->d_lane_sidx.bytes + pl->d_lane_xat.bytes + pl->d_lane_ctr.bytes;
-    }
-    pl->use_lane = pl->use_lane && max_lane != 0;
+    uint64_t max_seg = 0;
+    for (const SubBatch &sb : pl->subs)
+        max_seg = std::max<uint64_t>(max_seg, sb.cseg);
     if (pl->use_seg && max_seg) {
         if (!pl->d_seg_tok.ensure(max_seg * SG_NS * SG_TOKCAP * 4ull) ||
             !pl->d_seg_sidx.ensure(max_seg * SG_NS * SG_TRACE * 2ull)) {
@@ -1243,15 +1164,19 @@ static ZlibReturn plan_create(zsc_hip_deflate_plan **plan_out, U32 count, const 
               pl->d_plans.ensure(max_slots * sizeof(ZdBlockPlan)) &&
               pl->d_pout.ensure(max_count * sizeof(ZdParseOut)) &&
               pl->d_res.ensure((uint64_t)std::max(1u, count) * sizeof(ZdResult));
-    if (ok && (pl->use_lane || (SG_ENT16 && max_seg != 0)))
-        ok = pl->d_sorted16.ensure(tile_words * 2);
-    if (ok && pl->use_lane)
-        ok = pl->d_meta.ensure(max_rank_span * 8);
+    /* the match table: levels 4-9 with the default window and hash size, for the buffers the
+     * segmented parser takes; the match-finding strategies (default, filtered, fixed) share it */
+    pl->use_table = getenv("ZSC_HIP_NO_TABLE") == nullptr && pl->use_seg && max_seg != 0 && wbits == 15 &&
+                    mem_level == 8 && strategy != Z_HUFFMAN_ONLY && strategy != Z_RLE;
+    if (const char *e = getenv("ZSC_HIP_TABLE_CAP")) /* (debugging / tuning aid) */
+        pl->table_cap = (uint32_t)atoi(e);
+    if (ok && pl->use_table)
+        ok = pl->d_r2.ensure(max_rank_span * 4) && pl->d_rl.ensure(max_rank_span * 4);
     if (!ok) {
         zsc_hip_deflate_plan_destroy(pl);
         return Z_MEM_ERROR;
     }
-    pl->scratch_bytes += pl->d_sorted16.bytes + pl->d_meta.bytes;
+    pl->scratch_bytes += pl->d_r2.bytes + pl->d_rl.bytes;
     pl->scratch_bytes += pl->d_sorted.bytes + pl->d_tmp_syms.bytes + pl->d_rank.bytes + pl->d_hib.bytes + pl->d_cnt.bytes +
                          pl->d_dir.bytes + pl->d_recs.bytes + pl->d_plans.bytes +
                          pl->d_pout.bytes + pl->d_res.bytes;
@@ -1320,10 +1245,19 @@ extern "C" ZlibReturn zsc_hip_deflate_plan_run(zsc_hip_deflate_plan *pl, const v
         if (!simple) {
             hipLaunchKernelGGL(k_hash_sort, dim3(sb.ntiles), dim3(HS_WAVES * 64), 0, st, in, bufs,
                                (const uint32_t *)sb.d_tile_owner.p, sorted, tmp_syms, rank, dir,
-                               (uint16_t *)pl->d_sorted16.p, sb.ntiles);
+                               sb.ntiles);
             hipLaunchKernelGGL(k_link_prev, dim3(sb.ntiles), dim3(HS_WAVES * 64), 0, st, in, bufs,
                                (const uint32_t *)sb.d_tile_owner.p, (const uint16_t *)dir,
-                               (const uint16_t *)rank, hib, cnt, (uint64_t *)pl->d_meta.p, sb.ntiles);
+                               (const uint16_t *)rank, hib, cnt, sb.ntiles);
+        }
+        mark();
+        if (!simple) {
+            if (pl->use_table && sb.cseg > 0)
+                hipLaunchKernelGGL(k_match_table, dim3(sb.ntiles), dim3(MT_WAVES * 64), 0, st, in, bufs,
+                                   (const uint32_t *)sb.d_tile_owner.p, (const uint32_t *)sorted,
+                                   (const uint16_t *)rank, (const uint16_t *)hib, (const uint32_t *)cnt,
+                                   (uint32_t *)pl->d_r2.p, (uint32_t *)pl->d_rl.p, cfg, pl->table_min,
+                                   pl->table_cap, sb.ntiles);
         }
         mark();
         if (simple) {
@@ -1337,24 +1271,16 @@ extern "C" ZlibReturn zsc_hip_deflate_plan_run(zsc_hip_deflate_plan *pl, const v
                        (const uint32_t *)sb.d_order.p, (const uint32_t *)sorted,                 \
                        (const uint16_t *)rank, (const uint16_t *)hib, tmp_syms, recs, pout,      \
                        (const ZdSched *)pl->d_sched.p, cfg, (uint32_t)(FIRST), (uint32_t)(COUNT))
-            if (sb.clane > 0) {
-                (void)hipMemsetAsync(pl->d_lane_ctr.p, 0, 4, st);
-                hipLaunchKernelGGL(k_parse_lane, dim3(std::min(sb.clane, pl->lane_grid)), dim3(SL_W * 64), 0, st,
-                                   in, bufs, (const uint32_t *)sb.d_order.p, (const uint32_t *)sorted,
-                                   (const uint16_t *)pl->d_sorted16.p, (const uint64_t *)pl->d_meta.p,
-                                   tmp_syms, recs, pout,
-                                   (uint32_t *)pl->d_lane_tok.p, (uint16_t *)pl->d_lane_sidx.p,
-                                   (uint32_t *)pl->d_lane_xat.p, (uint32_t *)pl->d_lane_ctr.p, cfg, 0u,
-                                   sb.clane);
-            }
-            if (sb.cseg > sb.clane) {
+            if (sb.cseg > 0) {
                 auto kern = (pl->wbits == 15 && pl->mem_level == 8) ? k_parse_seg<false> : k_parse_seg<true>;
-                hipLaunchKernelGGL(kern, dim3(sb.cseg - sb.clane), dim3(SG_W * 64), 0, st, in, bufs,
+                hipLaunchKernelGGL(kern, dim3(sb.cseg), dim3(SG_W * 64), 0, st, in, bufs,
                                    (const uint32_t *)sb.d_order.p, (const uint32_t *)sorted,
                                    (const uint16_t *)rank, (const uint16_t *)hib,
-                                   (const uint32_t *)cnt, (const uint16_t *)pl->d_sorted16.p, tmp_syms, recs,
+                                   (const uint32_t *)cnt,
+                                   pl->use_table ? (const uint32_t *)pl->d_r2.p : nullptr,
+                                   pl->use_table ? (const uint32_t *)pl->d_rl.p : nullptr, tmp_syms, recs,
                                    pout, (uint32_t *)pl->d_seg_tok.p, (uint16_t *)pl->d_seg_sidx.p,
-                                   (const ZdSched *)pl->d_sched.p, cfg, sb.clane, sb.cseg - sb.clane);
+                                   (const ZdSched *)pl->d_sched.p, cfg, 0u, sb.cseg);
             }
             if (pl->d_sched.p) { /* runs with joints: the parsers keep a hole map (lz_parse.h) */
                 ZSC_LAUNCH_PARSE(LzLdsJ, sb.cseg, sb.c36 - sb.cseg);
@@ -1478,12 +1404,8 @@ extern "C" void zsc_hip_deflate_plan_destroy(zsc_hip_deflate_plan *pl)
     pl->d_cnt.release();
     pl->d_seg_tok.release();
     pl->d_seg_sidx.release();
-    pl->d_lane_tok.release();
-    pl->d_lane_sidx.release();
-    pl->d_lane_xat.release();
-    pl->d_lane_ctr.release();
-    pl->d_sorted16.release();
-    pl->d_meta.release();
+    pl->d_r2.release();
+    pl->d_rl.release();
     pl->d_sched.release();
     pl->d_dir.release();
     pl->d_recs.release();
