@@ -18,7 +18,7 @@ struct uint4 { uint32_t x, y, z, w; };
 #include "../../zsc_amd/csrc/lz_parse.h"
 /* event counters for tools/seg_stats.py: [0] batches, [1] long compares; per segment a
  * record (segment | redo flag, batches) is appended to g_sg_log */
-extern "C" { unsigned long long g_sg_cnt[8]; unsigned g_sg_log[1 << 20]; unsigned g_sg_nlog; }
+extern "C" { unsigned long long g_sg_cnt[16]; unsigned g_sg_log[1 << 20]; unsigned g_sg_nlog; }
 static unsigned long long g_sg_mark;
 static inline void sg_count(int what, unsigned n)
 {
@@ -72,7 +72,7 @@ struct EmuChains {
     std::vector<uint32_t> sorted, tmp;
     std::vector<uint16_t> rank, dir, hib;
     std::vector<uint32_t> cnt;
-    std::vector<uint32_t> r2, rl; /* the match table, when built */
+    std::vector<uint32_t> r2; /* the match table, when built */
 };
 
 static void build_chains(EmuChains &c, const uint8_t *src, uint32_t n)
@@ -125,20 +125,20 @@ static void build_chains(EmuChains &c, const uint8_t *src, uint32_t n)
 
 /* kernel 1c (match_table.h), as k_match_table runs it: only with the default window and hash size,
  * levels 4-9, a match-finding strategy; switched with emu_set_table */
+static uint32_t g_stair_min = 0; /* (the emulation searches every chain as a staircase unless told otherwise) */
+extern "C" void emu_set_stair_min(uint32_t v) { g_stair_min = v; }
 static int g_use_table = 1;
 static uint32_t g_mt_cap = MT_CAP;
 extern "C" void emu_set_table_cap(uint32_t cap) { g_mt_cap = cap; }
 extern "C" void emu_set_table(int on) { g_use_table = on; }
-extern "C" { unsigned long long g_mt_cnt[4]; } /* [0] r2 entries, [1] incomplete ones, [2] rl entries searched, [3] incomplete ones */
+extern "C" { unsigned long long g_mt_cnt[4]; } /* [0] entries, [1] incomplete ones, [2] ones that also answer for longer prev_lengths */
 static void build_table(EmuChains &c, int level, int strategy)
 {
     c.r2.clear();
-    c.rl.clear();
     const ZdLevel cfg = level_cfg(level);
     if (!g_use_table || !cfg.slow || cfg.wsize != ZD_TILE || cfg.hbits != 15u || strategy == 2 || strategy == 3)
         return;
     c.r2.assign((size_t)c.n + 64, 0xdeadbeefu);
-    c.rl.assign((size_t)c.n + 64, 0xdeadbeefu);
     MtLds *lds = (MtLds *)malloc(sizeof(MtLds));
     for (uint32_t t = 0; t < c.ntiles && t * ZD_TILE < c.n; t++) {
         memset(lds, 0x3C, sizeof(MtLds));
@@ -151,33 +151,111 @@ static void build_table(EmuChains &c, int level, int strategy)
         job.hib = c.hib.data();
         job.cnt = c.cnt.data();
         job.r2 = c.r2.data();
-        job.rl = c.rl.data();
         job.cfg = cfg;
         job.strategy = (uint32_t)strategy;
         job.cap = g_mt_cap;
         for (int w = 0; w < MT_WAVES; w++)
             mt_phase_load(job, lds, w);
         const uint32_t base0 = sg_base(job.cfg, job.start, job.n);
-        const uint32_t left = job.n - job.start;
-        const uint32_t nchunk = ((left < ZD_TILE ? left : ZD_TILE) + MT_CHUNK - 1u) / MT_CHUNK;
-        for (uint32_t ch = 0; ch < nchunk; ch++) {
-            for (int w = 0; w < MT_WAVES; w++)
-                mt_phase_stage(job, lds, w, ch);
-            for (int w = 0; w < MT_WAVES; w++)
-                mt_phase_search(job, lds, w, ch, 0u, base0);
-            for (int w = 0; w < MT_WAVES; w++)
-                mt_phase_search(job, lds, w, ch, 1u, base0);
-        }
+        for (int w = 0; w < MT_WAVES; w++)
+            mt_phase_search(job, lds, w, base0);
     }
     free(lds);
     for (uint32_t p = 0; p < c.n; p++) {
         g_mt_cnt[0]++;
         g_mt_cnt[1] += (c.r2[p] & MT_INCOMPLETE) != 0;
-        if (p && !(c.r2[p - 1] & MT_INCOMPLETE) && MT_LEN(c.r2[p - 1]) >= 3 && MT_LEN(c.r2[p - 1]) < cfg.lazy) {
-            g_mt_cnt[2]++;
-            g_mt_cnt[3] += (c.rl[p] & MT_INCOMPLETE) != 0;
+        g_mt_cnt[2] += (c.r2[p] & MT_RLOK) != 0;
+    }
+}
+
+
+/* Every complete entry of the match table against longest_match done the reference's way (the walk
+ * along p's own chain with its budget, src/deflate.c:1400-1518): returns the number of entries that
+ * differ; *incomplete = entries left to the parser.  An entry flagged MT_RLOK is also checked
+ * for the prev_length the lazy parse would ask with (the length in the entry before it). */
+static uint32_t emu_chain_entry(const EmuChains &c, uint32_t p, uint32_t v)
+{
+    const uint32_t cn = c.cnt[p], nA = cn & 0xffffu;
+    const uint32_t *run = c.sorted.data() + (size_t)(p >> 15) * ZD_TILE;
+    if (v < nA)
+        return (p & ~ZD_TILE_MASK) + (run[c.rank[p] - 1u - v] & ZD_TILE_MASK);
+    return (p & ~ZD_TILE_MASK) - ZD_TILE + ((run - ZD_TILE)[c.hib[p] - (v - nA)] & ZD_TILE_MASK);
+}
+static uint32_t emu_ref_longest_match(const EmuChains &c, const ZdLevel &cfg, uint32_t p, uint32_t b0, int strategy)
+{
+    const uint32_t n = c.n;
+    if ((uint64_t)p + 3u > n || b0 >= cfg.lazy)
+        return MT_NONE;
+    const uint32_t look = n - p, cn = c.cnt[p], total = (cn & 0xffffu) + (cn >> 16);
+    if (!total)
+        return MT_NONE;
+    const uint32_t base = sg_base(cfg, p, n);
+    const uint32_t floor_pos = p - base > ZD_MAX_DIST ? p - ZD_MAX_DIST : base;
+    const uint32_t q0 = emu_chain_entry(c, p, 0);
+    if (!(q0 > base && p - q0 <= ZD_MAX_DIST) || b0 >= look)
+        return MT_NONE;
+    const uint32_t cap = look < 258u ? look : 258u, nice = cfg.nice < look ? cfg.nice : look;
+    uint32_t budget = b0 >= cfg.good ? (uint32_t)cfg.chain >> 2 : cfg.chain;
+    const uint8_t *in = c.in.data();
+    uint32_t best = b0, where = 0;
+    for (uint32_t v = 0; v < total; v++) {
+        const uint32_t q = emu_chain_entry(c, p, v);
+        if (v && !(q > floor_pos))
+            break;
+        if (in[q + best] == in[p + best] && in[q + best - 1] == in[p + best - 1] && in[q] == in[p] && in[q + 1] == in[p + 1]) {
+            uint32_t len = 2;
+            while (len < cap && in[q + len] == in[p + len])
+                len++;
+            if (len > best) {
+                best = len;
+                where = q;
+                if (len >= nice)
+                    break;
+            }
+            if (--budget == 0)
+                break;
         }
     }
+    uint32_t len = best < look ? best : look;
+    if (len <= 5u) {
+        if (strategy == 1)
+            len = 2;
+        else if (len == 3u && p - where > ZD_TOO_FAR)
+            len = 2;
+    }
+    if (len <= b0 || best == b0)
+        return MT_NONE;
+    return MT_PACK(len, p - where);
+}
+extern "C" int emu_table_check(const uint8_t *src, uint32_t n, int level, int strategy, uint32_t *incomplete)
+{
+    EmuChains c;
+    build_chains(c, src, n);
+    build_table(c, level, strategy);
+    *incomplete = 0;
+    if (c.r2.empty())
+        return -1;
+    const ZdLevel cfg = level_cfg(level);
+    int bad = 0;
+    for (uint32_t p = 0; p < n; p++) {
+        const uint32_t e = c.r2[p];
+        if (e & MT_INCOMPLETE) {
+            (*incomplete)++;
+            continue;
+        }
+        if ((e & 0xffffffu) != emu_ref_longest_match(c, cfg, p, 2u, strategy))
+            bad++;
+        if ((e & MT_RLOK) && p && !(c.r2[p - 1] & MT_INCOMPLETE)) {
+            const uint32_t key = MT_LEN(c.r2[p - 1]);
+            if (key >= 3u && key < cfg.lazy) {
+                const uint32_t want = emu_ref_longest_match(c, cfg, p, key, strategy);
+                const uint32_t got = MT_LEN(e) > key ? (e & 0xffffffu) : MT_NONE;
+                if (want != got)
+                    bad++;
+            }
+        }
+    }
+    return bad;
 }
 
 int g_seg_mode = 0; /* 0: runtime's choice, 1: force wave-per-buffer, 2: segmented, segments handed out last first,
@@ -307,7 +385,7 @@ extern "C" int emu_parse(const uint8_t *src, uint32_t n, int level, int strategy
     job.hib = c.hib.data();
     job.cnt = c.cnt.data();
     job.r2 = c.r2.empty() ? nullptr : c.r2.data();
-    job.rl = c.rl.empty() ? nullptr : c.rl.data();
+    job.stair_min = g_stair_min;
     job.syms = syms;
     job.blocks = blocks;
     job.out = &out;
@@ -361,7 +439,7 @@ extern "C" int emu_compress(const uint8_t *src, uint32_t n, int level, int wrap,
     job.hib = c.hib.data();
     job.cnt = c.cnt.data();
     job.r2 = c.r2.empty() ? nullptr : c.r2.data();
-    job.rl = c.rl.empty() ? nullptr : c.rl.data();
+    job.stair_min = g_stair_min;
     job.syms = syms.data();
     job.blocks = recs.data();
     job.out = &po;
@@ -459,8 +537,9 @@ struct EmuSecRunner {
             if (r.sched.empty())
                 build_table(c, level, strategy);
             job.r2 = c.r2.empty() ? nullptr : c.r2.data();
-            job.rl = c.rl.empty() ? nullptr : c.rl.data();
-            job.syms = syms.data();
+            job.stair_min = g_stair_min;
+    job.stair_min = g_stair_min;
+                    job.syms = syms.data();
             job.blocks = recs.data();
             job.out = &po;
             job.cfg = level_cfg(level);

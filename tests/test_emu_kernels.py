@@ -148,6 +148,59 @@ def test_segmented_parser_hand_over_orders(emu, oracle):
         emu.emu_set_seg_mode(0)
 
 
+def test_match_table_entries_against_the_reference_walk(emu, oracle):
+    """match_table.h: every entry the table kernel completes equals longest_match done the
+    reference's way (the walk along the position's own chain with its chain budget), for
+    prev_length 2 and -- where the entry says it answers for longer ones too -- for the length the
+    lazy parse would ask with.  What the kernel leaves incomplete the parser searches itself."""
+    if emu.inflate_only or emu.group16:
+        pytest.skip("the table kernel is whole-wave code: 64 lanes only")
+    inc = C.c_uint32()
+    try:
+        for cap in (8, 16, 64):
+            emu.emu_set_table_cap(cap)
+            for kind, n, level, strat in (("text", 70001, 6, 0), ("bitmap", 40000, 6, 0), ("runs", 30000, 9, 0),
+                                          ("table", 66000, 4, 0), ("object", 38240, 6, 1), ("zero", 70000, 6, 0),
+                                          ("random", 5000, 8, 0), ("text", 300, 5, 4), ("token", 3, 6, 0),
+                                          ("text", 0, 6, 0)):
+                if cap != 16 and n > 40000:
+                    continue
+                data = corpus.make_buffer(kind, n, n + cap)
+                bad = emu.emu_table_check(data, n, level, strat, C.byref(inc))
+                assert bad == 0, (cap, kind, n, level, strat)
+                assert n < 1000 or inc.value < n   # (and something is complete)
+    finally:
+        emu.emu_set_table_cap(16)
+
+
+def test_segmented_parser_search_modes(emu, oracle):
+    """The segmented parser's three ways to a match give the reference's stream: hops over the match
+    table (on / off), the staircase search over the shortest chains (for every chain / for long ones
+    only, the product's default / never), the reference's own walk."""
+    if emu.inflate_only or emu.group8:
+        pytest.skip("the segmented parser is exercised at 64 and 16 lanes")
+    try:
+        emu.emu_set_seg_mode(2)
+        for table in (1, 0):
+            for stair_min in (0, 256, 0xffffffff):
+                emu.emu_set_table(table)
+                emu.emu_set_stair_min(stair_min)
+                for kind, n in (("text", 90000), ("bitmap", 70000), ("table", 40000), ("runs", 30000), ("zero", 70000),
+                                ("random", 20000), ("object", 38240), ("text", 65275)):
+                    data = corpus.make_buffer(kind, n, n + table)
+                    for level in (6, 9, 4) if n <= 40000 else (6,):
+                        if emu.group16:
+                            assert parse_equals_oracle(emu, oracle, data, level), (table, stair_min, kind, n, level)
+                            continue
+                        rc, got = emu_compress(emu, data, level, 1)
+                        orc, want, _ = oracle.compress(data, level)
+                        assert rc == orc == 0 and got == want, (table, stair_min, kind, n, level)
+    finally:
+        emu.emu_set_seg_mode(0)
+        emu.emu_set_table(1)
+        emu.emu_set_stair_min(0)
+
+
 def emu_uncompress(L, data, cap, wb):
     dst = C.create_string_buffer(max(cap, 1))
     ol, used = C.c_uint32(), C.c_uint32()

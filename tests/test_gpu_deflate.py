@@ -385,3 +385,34 @@ def test_gzip_trailer_crc_of_many_lengths(oracle):
     assert rc == 0 and all(s == 0 for s in stats)
     for b, o in zip(bufs, outs):
         assert o == oracle.compress(b, 6, window_bits=31)[1], len(b)
+
+
+@pytest.mark.gpu
+def test_match_table_and_search_modes_on_the_device(oracle):
+    """The match table (kernel 1c, opt-in: ZSC_HIP_TABLE) and the staircase search with and without its
+    length threshold: the streams are the oracle's in every combination."""
+    import zsc_amd
+    bufs = [corpus.make_buffer(k, n, n + 1) for k, n in (("text", 200001), ("bitmap", 150000), ("table", 98304),
+                                                        ("runs", 70000), ("zero", 66000), ("object", 38240),
+                                                        ("random", 30000), ("text", 3100), ("text", 65275))]
+    want = {}
+    keep = {k: os.environ.get(k) for k in ("ZSC_HIP_TABLE", "ZSC_HIP_TABLE_CAP", "ZSC_HIP_STAIR_MIN")}
+    try:
+        for table, cap, stair_min in ((1, 16, 256), (1, 8, 0), (1, 64, 100000), (0, 0, 0), (0, 0, 100000), (0, 0, 256)):
+            os.environ.pop("ZSC_HIP_TABLE", None)
+            if table:
+                os.environ["ZSC_HIP_TABLE"] = "1"
+                os.environ["ZSC_HIP_TABLE_CAP"] = str(cap)
+            os.environ["ZSC_HIP_STAIR_MIN"] = str(stair_min)
+            for level, strat in ((6, 0), (9, 0), (4, 1), (5, 4)):
+                rc, outs, stats = zsc_amd.compress_batch(bufs, level=level, strategy=strat)
+                assert rc == 0
+                for i, (b, o, st) in enumerate(zip(bufs, outs, stats)):
+                    if (i, level, strat) not in want:
+                        want[(i, level, strat)] = oracle.compress(b, level, strategy=strat)[1]
+                    assert st == 0 and o == want[(i, level, strat)], (table, cap, stair_min, level, strat, i)
+    finally:
+        for k, v in keep.items():
+            os.environ.pop(k, None)
+            if v is not None:
+                os.environ[k] = v

@@ -4,7 +4,7 @@
 import sys, os, subprocess
 if len(sys.argv) > 4 and os.environ.get("ZSC_PROBE_CHILD") is None:
     for cap in sys.argv[4:]:
-        env = dict(os.environ, ZSC_HIP_TABLE_CAP=cap, ZSC_PROBE_CHILD="1")
+        env = dict(os.environ, ZSC_HIP_TABLE="1", ZSC_HIP_TABLE_CAP=cap, ZSC_PROBE_CHILD="1")
         subprocess.run([sys.executable, sys.argv[0]] + sys.argv[1:4], env=env, check=True)
     sys.exit(0)
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))

@@ -11,7 +11,7 @@ kind, size = sys.argv[1], int(sys.argv[2])
 level = int(sys.argv[3]) if len(sys.argv) > 3 else 6
 waves = int(sys.argv[4]) if len(sys.argv) > 4 else 8
 data = corpus.make_buffer(kind, size, 1)
-cnt = (C.c_ulonglong * 4).in_dll(E, "g_sg_cnt"); log = (C.c_uint * (1 << 20)).in_dll(E, "g_sg_log")
+cnt = (C.c_ulonglong * 16).in_dll(E, "g_sg_cnt"); log = (C.c_uint * (1 << 20)).in_dll(E, "g_sg_log")
 nlog = C.c_uint.in_dll(E, "g_sg_nlog")
 E.emu_set_seg_mode(2)
 cap = size + (size >> 3) + 256

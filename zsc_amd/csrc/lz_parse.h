@@ -85,8 +85,8 @@ typedef struct {
     const uint16_t *rank;   /* this buffer: index of a position in its tile's sorted array */
     const uint16_t *hib;    /* this buffer: last index of the position's bucket in the previous tile */
     const uint32_t *cnt;    /* this buffer: chain lengths in the own | previous tile (hash_sort.h) */
-    const uint32_t *r2;     /* this buffer: longest_match(p, 2) per position (match_table.h), or null */
-    const uint32_t *rl;     /* this buffer: longest_match(p, length in r2[p-1]) per position, or null */
+    uint32_t stair_min;     /* segmented parser: chains at least this long are searched as a staircase (lz_parse_seg.h) */
+    const uint32_t *r2;     /* this buffer: the match table, longest_match(p, 2) per position (match_table.h), or null */
     uint32_t *syms;         /* this buffer's symbol slots */
     ZdBlockRec *blocks;     /* this buffer's block records */
     ZdParseOut *out;

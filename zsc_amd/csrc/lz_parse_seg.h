@@ -40,6 +40,14 @@
 
 #include "lz_parse.h"
 
+/* -DSG_GROUP=16 builds this parser for four 16-lane groups per wavefront (wave_group.h): four
+ * segments parsed at once by one wave, sharing every instruction they execute at the same time */
+#ifdef SG_GROUP
+#undef ZSC_GROUP
+#define ZSC_GROUP SG_GROUP
+#include "wave_group.h"
+#endif
+
 #ifndef SG_COUNT
 #define SG_COUNT(what, n) /* event counters of the host emulation (tests/emu) */
 #endif
@@ -62,6 +70,16 @@
 #endif
 #define SG_TRACE SG_G               /* positions a segment records (its own) */
 #define SG_TOKCAP (SG_G + SG_OV + 320u) /* tokens one segment's parser can emit */
+
+#ifndef SG_PICK_AHEAD
+#define SG_PICK_AHEAD 16u /* positions from p on whose chain lengths a search must find in the register cache */
+#endif
+#ifndef SG_STAIR_MIN
+#define SG_STAIR_MIN 256u /* chains at least this long are searched as a staircase (LzJob.stair_min) */
+#endif
+#ifndef SG_STAIR
+#define SG_STAIR 1 /* 0: every search is the reference's walk along p's own chain (the parser as it was) */
+#endif
 
 #define SG_EXIT_SYNCED 1u
 #define SG_EXIT_UNSYNCED 2u
@@ -508,8 +526,9 @@ DEV void sg_phase_begin(const LzJob &job, SgLds *lds, int w)
 #define SGH_VALID 0x80000000u
 #define SGH_MATCH 0x40000000u /* literals (bits 28-29 say how many), then the match in bits 0-23 (MT_LEN / MT_DIST) */
 
-/* rl of position X for the length KEY, given A = r2[X]: r2 answers itself where it may (MT_RLOK) */
-#define SG_RL(X, A, KEY) (((A)&MT_RLOK) ? (MT_LEN(A) > (KEY) ? (A) : MT_NONE) : job.rl[X])
+/* longest_match at position X for prev_length KEY, given A = r2[X]: the same match if it is longer,
+ * none otherwise -- where the entry says that holds (MT_RLOK) */
+#define SG_RL(X, A, KEY) (((A)&MT_RLOK) ? (MT_LEN(A) > (KEY) ? (A) : MT_NONE) : MT_INCOMPLETE)
 
 /* hops of positions X0 .. X0+GRP-1: LV(hop), and the four input bytes at each position LV(hby) */
 #define SG_HOP_LOAD(X0)                                                                       \
@@ -729,7 +748,7 @@ DEV void sg_parse_segment(const LzJob &job, SgLds *lds, const SgScratch &scr, ui
         const uint32_t prev_len = cur_len, prev_at = cur_at;
         cur_len = 2;
         if (look >= 3 && prev_len < job.cfg.lazy) {
-            if (p - mt_at >= GRP) {
+            if (p - mt_at >= GRP - SG_PICK_AHEAD) { /* (and the positions a search may choose its chain from) */
                 mt_at = p;
                 FOR_GLANES
                 {
@@ -746,7 +765,7 @@ DEV void sg_parse_segment(const LzJob &job, SgLds *lds, const SgScratch &scr, ui
                 const int32_t hiA = (int32_t)(rh & 0xffffu) - 1, hiB = (int32_t)(rh >> 16);
                 const uint32_t tileA = p & ~ZD_TILE_MASK;
                 const uint32_t *runA = job.sorted + (uint64_t)(p >> 15) * ZD_TILE;
-                const uint32_t floor_pos = p - st.base > job.cfg.max_dist ? p - job.cfg.max_dist : st.base;
+                uint32_t floor_pos = p - st.base > job.cfg.max_dist ? p - job.cfg.max_dist : st.base;
                 const uint32_t cap = look < 258u ? look : 258u;
                 const uint32_t nice = job.cfg.nice < look ? job.cfg.nice : look;
                 uint32_t best = prev_len, where = cur_at, sb = 0;
@@ -761,7 +780,10 @@ DEV void sg_parse_segment(const LzJob &job, SgLds *lds, const SgScratch &scr, ui
                 LANEVAR(uint32_t, f2);
                 LANEVAR(uint32_t, f3);
                 SG_LOAD(e0, 0u);
-                if (total > GRP) { /* most chains of text fit one load */
+                /* a long chain is searched as a staircase over shorter ones (below); a short one is
+                 * walked as the reference walks it, 64 candidates a step */
+                const int stair = SG_STAIR && job.cfg.hbits == 15u && total >= job.stair_min;
+                if (!stair && total > GRP) { /* most chains of text fit one load */
                     SG_LOAD(e1, 1u);
                     SG_LOAD(e2, 2u);
                     SG_LOAD(e3, 3u);
@@ -790,6 +812,152 @@ DEV void sg_parse_segment(const LzJob &job, SgLds *lds, const SgScratch &scr, ui
                         sb &= 0xffffu;
                     }
                 }
+                if (!fin && stair) {
+                    /* ---- the search as a staircase (match_table.h has the argument) ----------------
+                     * A candidate that fails the pre-check is free, so while the chain budget lasts the
+                     * walk's result is: the nearest candidate longer than best, then the nearest one
+                     * beyond it that is longer still, ...  A candidate longer than best shares best + 1
+                     * bytes with p and so lies on the chain of every position p + j, j <= best - 2,
+                     * shifted by j: each step walks the SHORTEST of those chains (of the ones whose
+                     * lengths are in the register cache) instead of p's own.  Whether the budget could
+                     * have ended the reference's walk before the last step is checked afterwards; if it
+                     * could, the walk is done the reference's way, down to the last step's candidate. */
+                    const uint32_t budget0 = budget;
+                    uint32_t bnd = p, nrec = 0, qs = best >= 5u ? p : 0xffffffffu;
+                    int more = 1;
+                    while (more) {
+                        more = 0;
+                        uint32_t j = 0;
+                        if (best >= 3u) {
+                            /* the shortest chain among those whose lengths are in the register cache */
+                            LANEVAR(uint32_t, tkey);
+                            LANEVAR(int, ismin);
+                            const uint32_t l0 = p - mt_at, l1 = l0 + (best - 2u);
+                            FOR_GLANES
+                            {
+                                const uint32_t l = (uint32_t)GLANE, c = LV(mcn);
+                                LV(tkey) = (l >= l0 && l <= l1 && (uint64_t)mt_at + l + 3u <= job.n)
+                                               ? (c & 0xffffu) + (c >> 16)
+                                               : 0xffffffffu;
+                            }
+                            const uint32_t tmin = GMIN_U32(tkey);
+                            FOR_GLANES { LV(ismin) = LV(tkey) == tmin; }
+                            j = (uint32_t)CTZ64(GBALLOT(ismin)) - l0;
+                        }
+                        const uint32_t cnj = GREADLANE(mcn, p + j - mt_at), rhj = GREADLANE(mrk, p + j - mt_at);
+                        const uint32_t nAj = cnj & 0xffffu, totj = nAj + (cnj >> 16);
+                        const int32_t hiAj = (int32_t)(rhj & 0xffffu) - 1, hiBj = (int32_t)(rhj >> 16);
+                        const uint32_t tileJ = (p + j) & ~ZD_TILE_MASK;
+                        const uint32_t *runJ = job.sorted + (uint64_t)((p + j) >> 15) * ZD_TILE;
+                        if (best <= 3u) /* the two bytes are among the four read at p */
+                            sb = (s0123 >> (8u * (best - 1u))) & 0xffffu;
+                        else {
+                            SG_PEEK32(p + best - 1, sb);
+                            sb &= 0xffffu;
+                        }
+                        int found = 0, gone = 0;
+                        for (uint32_t bb = 0; bb * GRP < totj && !found && !gone; bb++) {
+                            LANEVAR(uint32_t, ej);
+                            LANEVAR(uint32_t, _q);
+                            LANEVAR(uint32_t, _w0);
+                            LANEVAR(int, _pass);
+                            LANEVAR(int, _gone);
+                            if (j == 0u && bb == 0u) {
+                                FOR_GLANES { LV(ej) = LV(e0); }
+                            } else {
+                                FOR_GLANES
+                                {
+                                    const uint32_t _v = bb * GRP + (uint32_t)GLANE;
+                                    int32_t _i = _v < nAj ? hiAj - (int32_t)_v : hiBj - (int32_t)(_v - nAj) - (int32_t)ZD_TILE;
+                                    _i = _v < totj ? _i : 0;
+                                    LV(ej) = runJ[_i];
+                                }
+                            }
+                            SG_COUNT(0, 1);
+                            FOR_GLANES
+                            {
+                                const uint32_t _v = bb * GRP + (uint32_t)GLANE;
+                                const uint32_t qj = tileJ + (LV(ej) & ZD_TILE_MASK) - (_v < nAj ? 0u : ZD_TILE);
+                                const uint32_t q = qj - j;
+                                const int have = _v < totj;
+                                /* the chain leaves the buffer or the window (:1519) */
+                                const int g = have && (qj < j || (q < bnd && !(q > floor_pos || q == q0)));
+                                /* (an entry newer than the last step's candidate was seen at an earlier level) */
+                                const int live = have && !g && q < bnd;
+                                const uint32_t r0 = live ? lz_ridx<L>(st, q) : 0u;
+                                const uint32_t r1 = live ? lz_ridx<L>(st, q + best - 1) : 0u;
+                                const uint32_t w0 = lds_u32(lds->ring, r0);
+                                const uint32_t g1 = lds_u32(lds->ring, r1) & 0xffffu;
+                                LV(_q) = q;
+                                LV(_w0) = w0;
+                                LV(_gone) = g;
+                                LV(_pass) = live && g1 == sb && ((w0 ^ s0123) & 0xffffffu) == 0u;
+                            }
+                            const uint64_t mgone = GBALLOT(_gone);
+                            uint64_t todo = GBALLOT(_pass);
+                            if (mgone != 0) {
+                                todo &= (mgone & (0ull - mgone)) - 1ull; /* what comes after the first such entry is older still */
+                                gone = 1;
+                            }
+                            while (todo != 0) {
+                                const int jl = CTZ64(todo);
+                                const uint32_t qx = GREADLANE(_q, jl);
+                                uint32_t len = 3;
+                                if (cap > 3u && GREADLANE(_w0, jl) == s0123)
+                                    SG_LCP(qx, len);
+                                if (len > best) {
+                                    found = 1;
+                                    where = qx;
+                                    best = len;
+                                    bnd = qx;
+                                    nrec++;
+                                    break;
+                                }
+                                todo &= todo - 1ull;
+                            }
+                        }
+                        if (found && best < nice) {
+                            more = 1;
+                            if (qs == 0xffffffffu && best >= 5u)
+                                qs = where;
+                        }
+                    }
+                    fin = 1;
+                    if (nrec != 0) {
+                        /* the budget is charged by the steps, and by candidates that pass the pre-check
+                         * without being longer: none while best_len <= 4, so at most as many as p's own
+                         * chain has entries between the first step to a level >= 5 and the last step */
+                        uint32_t between = 0;
+                        if (qs != 0xffffffffu && qs != where) {
+                            const uint32_t rk = rh & 0xffffu, hb = rh >> 16;
+                            const uint32_t r1 = GUNI((uint32_t)job.rank[where]);
+                            const uint32_t newer = (where >> 15) == (p >> 15) ? rk - 1u - r1 : nA + (hb - r1);
+                            if (qs == p) {
+                                between = newer;
+                            } else {
+                                const uint32_t r0 = GUNI((uint32_t)job.rank[qs]);
+                                between = newer - ((qs >> 15) == (p >> 15) ? rk - 1u - r0 : nA + (hb - r0)) - 1u;
+                            }
+                        }
+                        if (nrec + between >= budget0) {
+                            SG_COUNT(8, 1);
+                            /* the reference's walk, as far as the last step's candidate: nothing beyond it
+                             * is longer, so nothing beyond it changes the result */
+                            if (where - 1u > floor_pos)
+                                floor_pos = where - 1u;
+                            best = prev_len;
+                            where = cur_at;
+                            budget = budget0;
+                            fin = 0;
+                            if (best <= 3u)
+                                sb = (s0123 >> (8u * (best - 1u))) & 0xffffu;
+                            else {
+                                SG_PEEK32(p + best - 1, sb);
+                                sb &= 0xffffu;
+                            }
+                        }
+                    }
+                }
                 int sweep = 0;
                 if (total > 4u * GRP) {
                     /* a sweep step covers 16 GRP window positions, a walk step GRP candidates */
@@ -800,6 +968,11 @@ DEV void sg_parse_segment(const LzJob &job, SgLds *lds, const SgScratch &scr, ui
                 } else if (sweep) {
                     SG_SWEEP(q0);
                 } else {
+                    if (stair && total > GRP) {
+                        SG_LOAD(e1, 1u);
+                        SG_LOAD(e2, 2u);
+                        SG_LOAD(e3, 3u);
+                    }
                     for (uint32_t b0 = 0;; b0 += 4u) {
                         const int more = (b0 + 4u) * GRP < total;
                         if (more) {
@@ -1147,5 +1320,11 @@ DEV void sg_init(SgLds *lds, int w)
     }
     WAVE_SYNC();
 }
+
+#ifdef SG_GROUP
+#undef ZSC_GROUP
+#define ZSC_GROUP 64
+#include "wave_group.h"
+#endif
 
 #endif

@@ -49,23 +49,16 @@
 #ifndef MT_WAVES
 #define MT_WAVES 16
 #endif
+#ifndef MT_STEPS
+#define MT_STEPS 3u /* records a search follows before it is left to the parser */
+#endif
 #ifndef MT_CAP
-#define MT_CAP 48u /* entries a search looks at before it is left to the parser (MtJob.cap) */
+#define MT_CAP 16u /* entries of one chain a search looks at (MtJob.cap, a multiple of 4) */
 #endif
-#ifndef MT_WALK
-#define MT_WALK 8u /* entries a lane looks at per round */
-#endif
-#define MT_CHUNK ((uint32_t)MT_WAVES * WAVE) /* positions per step of the workgroup */
-#define MT_META (MT_CHUNK + 264u)             /* positions whose chain records are staged: one before the chunk, 258 + slack behind */
-#define MT_KEY_NONE 0xffffu
 
 struct MtLds {
     static constexpr uint32_t SPAN = 2u * ZD_TILE + 288u;
     uint8_t win[SPAN + 16];
-    uint32_t mcnt[MT_META];        /* cnt[] of the positions from one before the chunk on */
-    uint32_t mrh[MT_META];         /* rank | hib << 16 of the same */
-    uint16_t key[2][MT_CHUNK + 1]; /* length in r2 of the chunk's positions (slot 1 + i), double-buffered */
-    uint32_t queue[2];             /* next position of the chunk to search: r2, rl */
 };
 
 typedef struct {
@@ -75,10 +68,10 @@ typedef struct {
     const uint32_t *sorted; /* tile 0 of this buffer */
     const uint16_t *rank, *hib;
     const uint32_t *cnt;
-    uint32_t *r2, *rl; /* this buffer */
-    ZdLevel cfg;       /* window_bits 15 / mem_level 8 only */
+    uint32_t *r2; /* this buffer */
+    ZdLevel cfg;  /* window_bits 15 / mem_level 8 only */
     uint32_t strategy;
-    uint32_t cap; /* entries a search may look at before it is left to the parser */
+    uint32_t cap; /* entries of one chain a search may look at before it is left to the parser */
 } MtJob;
 
 /* phase 0: the window of the tile into LDS; bytes before the buffer are never addressed,
@@ -105,32 +98,6 @@ DEV void mt_phase_load(const MtJob &job, MtLds *lds, int w)
     }
 }
 
-/* before chunk c: the chain records of its positions (and of what a search can ask for around
- * them) into LDS, the two work queues back to their start */
-DEV void mt_phase_stage(const MtJob &job, MtLds *lds, int w, uint32_t c)
-{
-    const uint32_t m0 = job.start + c * MT_CHUNK - 1u; /* (wraps for the buffer's first chunk: slot 0 is not used then) */
-    for (uint32_t i0 = (uint32_t)w * WAVE; i0 < MT_META; i0 += MT_WAVES * WAVE) {
-        FOR_LANES
-        {
-            const uint32_t i = i0 + (uint32_t)LANE;
-            if (i < MT_META) {
-                const uint32_t x = m0 + i;
-                const int owner = !(i == 0 && m0 == 0xffffffffu) && (uint64_t)x + 3u <= job.n;
-                lds->mcnt[i] = owner ? job.cnt[x] : 0u;
-                lds->mrh[i] = owner ? (uint32_t)job.rank[x] | ((uint32_t)job.hib[x] << 16) : 0u;
-            }
-        }
-    }
-    if (w == 0) {
-        FOR_LANES
-        {
-            if (LANE < 2)
-                lds->queue[LANE] = 0;
-        }
-    }
-}
-
 /* longest common prefix of the strings at window indices iq and ip, at most cap bytes */
 DEV uint32_t mt_lcp(const uint8_t *win, uint32_t iq, uint32_t ip, uint32_t cap)
 {
@@ -146,377 +113,169 @@ DEV uint32_t mt_lcp(const uint8_t *win, uint32_t iq, uint32_t ip, uint32_t cap)
     return l < cap ? l : cap;
 }
 
-/* entry v (0 = newest) of the chain of a position with rank rk, link hb and nA earlier members in
- * its own tile, which starts at tpos: the absolute position it names */
-DEV uint32_t mt_entry(const MtJob &job, uint32_t tpos, uint32_t rk, uint32_t hb, uint32_t nA, uint32_t v)
+/* entry number i of the sorted array the chain of a position lies in (its own tile's, continued
+ * downwards by the previous tile's, which precedes it in memory): the tile-relative position it
+ * names.  Chain entry v of a position with rank rk, link hb and nA earlier members in its own tile
+ * is number rk - 1 - v for v < nA, and hb - ZD_TILE - (v - nA) after that. */
+DEV int32_t mt_slot(uint32_t rk, uint32_t hb, uint32_t nA, uint32_t v)
 {
-    const uint32_t *run = job.sorted + (uint64_t)(tpos >> 15) * ZD_TILE;
-    if (v < nA)
-        return tpos + (run[rk - 1u - v] & ZD_TILE_MASK);
-    return tpos - ZD_TILE + ((run - ZD_TILE)[hb - (v - nA)] & ZD_TILE_MASK);
+    return v < nA ? (int32_t)(rk - 1u - v) : (int32_t)(hb - (v - nA)) - (int32_t)ZD_TILE;
 }
 
-/* four entries at once, v .. v+3 (one 16-byte load where the four lie in one run of one tile);
- * entries past the end of the chain come back as 0xffffffff */
-typedef struct {
-    uint32_t q0, q1, q2, q3;
-} MtBlock;
-DEV MtBlock mt_block(const MtJob &job, uint32_t tpos, uint32_t rk, uint32_t hb, uint32_t nA, uint32_t tot, uint32_t v)
+/* longest_match(p, prev_length = 2) as a table entry; base0 = window base at the tile's start.
+ * Straight-line code with fixed trip counts: what does not fit them is left incomplete. */
+DEV uint32_t mt_search(const MtJob &job, const MtLds *lds, uint32_t p, uint32_t base0)
 {
-    MtBlock o;
-    const uint32_t *run = job.sorted + (uint64_t)(tpos >> 15) * ZD_TILE;
-    if (v + 4u <= nA) {
-        const uint32_t *e = run + (rk - 4u - v);
-        const uint32_t e0 = e[0], e1 = e[1], e2 = e[2], e3 = e[3];
-        o.q0 = tpos + (e3 & ZD_TILE_MASK);
-        o.q1 = tpos + (e2 & ZD_TILE_MASK);
-        o.q2 = tpos + (e1 & ZD_TILE_MASK);
-        o.q3 = tpos + (e0 & ZD_TILE_MASK);
-    } else if (v >= nA && v + 4u <= tot) {
-        const uint32_t *e = run - ZD_TILE + (hb - (v - nA) - 3u);
-        const uint32_t e0 = e[0], e1 = e[1], e2 = e[2], e3 = e[3];
-        o.q0 = tpos - ZD_TILE + (e3 & ZD_TILE_MASK);
-        o.q1 = tpos - ZD_TILE + (e2 & ZD_TILE_MASK);
-        o.q2 = tpos - ZD_TILE + (e1 & ZD_TILE_MASK);
-        o.q3 = tpos - ZD_TILE + (e0 & ZD_TILE_MASK);
-    } else {
-        o.q0 = v < tot ? mt_entry(job, tpos, rk, hb, nA, v) : 0xffffffffu;
-        o.q1 = v + 1u < tot ? mt_entry(job, tpos, rk, hb, nA, v + 1u) : 0xffffffffu;
-        o.q2 = v + 2u < tot ? mt_entry(job, tpos, rk, hb, nA, v + 2u) : 0xffffffffu;
-        o.q3 = v + 3u < tot ? mt_entry(job, tpos, rk, hb, nA, v + 3u) : 0xffffffffu;
-    }
-    return o;
-}
-
-/* number of entries of p's chain that are newer than q (q on the chain) */
-DEV uint32_t mt_index(const MtJob &job, uint32_t p, uint32_t rk, uint32_t hb, uint32_t nA, uint32_t q)
-{
-    const uint32_t rq = job.rank[q];
-    return (q >> 15) == (p >> 15) ? rk - 1u - rq : nA + (hb - rq);
-}
-
-/* ---- the searches of one chunk, a lane per search ------------------------------------------
- *
- * Searches differ in length by two orders of magnitude, and what they do at any moment differs
- * too: taking a position, choosing a chain, walking it, comparing a candidate that passed the
- * two-byte test, wrapping up.  Run as one loop per lane the wave would execute, in EVERY trip,
- * the most expensive thing any of its lanes wants.  So the lanes take positions off a queue --
- * one that is done with a short search starts the next -- and a round of the wave is a fixed
- * sequence of blocks, each executed once for all the lanes that want it.  The blocks are ordered
- * so that nothing a block loads from global memory is used before the NEXT round (walk, compare,
- * wrap up, new position, choose chain): a round costs its instructions, not its round trips. */
-#define MT_S_NEW 0u
-#define MT_S_PICK 1u
-#define MT_S_WALK 2u
-#define MT_S_LCP 3u
-#define MT_S_FIN 4u  /* the search is over: ask for what the budget test needs */
-#define MT_S_FIN2 5u /* write the entry */
-#define MT_S_IDLE 6u
-
-#define MT_K_INC 0x8000u  /* key slot: the position's r2 is incomplete */
-#define MT_K_RLOK 0x4000u /* key slot: the position's r2 answers for longer prev_lengths too */
-
-typedef struct {
-    LANEVAR(uint32_t, st);
-    LANEVAR(uint32_t, idx);   /* the item: position start + c * MT_CHUNK + idx (idx == MT_CHUNK: the position before the tile) */
-    LANEVAR(uint32_t, p);
-    LANEVAR(uint32_t, b0);
-    LANEVAR(uint32_t, res);   /* the entry, once known */
-    LANEVAR(uint32_t, q0);    /* head of p's chain: the entry as loaded while hd is set, the position after */
-    LANEVAR(uint32_t, hd);    /* the head has not been looked at yet */
-    LANEVAR(uint32_t, base);
-    LANEVAR(uint32_t, b);
-    LANEVAR(uint32_t, bnd);
-    LANEVAR(uint32_t, where);
-    LANEVAR(uint32_t, nrec);
-    LANEVAR(uint32_t, qs);    /* where the walk first stands at a level >= 5; in MT_S_FIN2: its rank */
-    LANEVAR(uint32_t, looked);
-    LANEVAR(uint32_t, j);     /* the chain being walked: that of p + j */
-    LANEVAR(uint32_t, rhj);   /* its rank | hib << 16 */
-    LANEVAR(uint32_t, cj);    /* its cnt */
-    LANEVAR(uint32_t, v);     /* next entry */
-    LANEVAR(uint32_t, sb);    /* the two bytes at p + b - 1 */
-    LANEVAR(uint32_t, qp);    /* the candidate to compare; in MT_S_FIN2: rank of the last record */
-    LANEVAR(MtBlock, cur);
-    LANEVAR(MtBlock, nxt);
-} MtWave;
-
-/* an entry to the table (and, for r2, its length and flags to the chunk's keys) */
-DEV void mt_store(const MtJob &job, MtLds *lds, uint32_t kind, uint32_t c, uint32_t npos, uint32_t idx, uint32_t p,
-                  uint32_t res)
-{
-    if (kind == 0u) {
-        if (idx < npos)
-            job.r2[p] = res;
-        lds->key[idx < npos ? (c & 1u) : 1u][idx < npos ? 1u + idx : MT_CHUNK] =
-            (uint16_t)((res & MT_INCOMPLETE) ? MT_K_INC : (MT_LEN(res) | ((res & MT_RLOK) ? MT_K_RLOK : 0u)));
-    } else {
-        job.rl[p] = res & ~MT_RLOK;
-    }
-}
-
-/* kind 0: r2 of the chunk's positions (and, in the tile's first chunk, of the position before the
- * tile, for its key); kind 1: rl, keyed by the length in r2 of the position before, where r2 of the
- * position itself does not answer for it */
-DEV void mt_phase_search(const MtJob &job, MtLds *lds, int w, uint32_t c, uint32_t kind, uint32_t base0)
-{
-    (void)w;
     const uint32_t n = job.n;
-    const uint32_t c0 = job.start + c * MT_CHUNK;
-    const uint32_t left = n - c0 < job.start + ZD_TILE - c0 ? n - c0 : job.start + ZD_TILE - c0;
-    const uint32_t npos = left < MT_CHUNK ? left : MT_CHUNK;
-    const uint32_t nitems = npos + ((kind == 0u && c == 0u && job.start != 0u) ? 1u : 0u);
+    if ((uint64_t)p + 3u > n)
+        return MT_NONE | MT_RLOK; /* :2027: fewer than three bytes ahead */
+    const uint32_t look = n - p; /* what matters of it: fill_window keeps MIN_LOOKAHEAD bytes ahead until the input ends */
+    const uint32_t cn = job.cnt[p];
+    const uint32_t nA = cn & 0xffffu, total = nA + (cn >> 16);
+    if (total == 0)
+        return MT_NONE | MT_RLOK;
+    const uint32_t rk = job.rank[p], hb = job.hib[p];
+    const uint32_t tileA = p & ~ZD_TILE_MASK;
+    uint32_t base = base0;
+    for (int k = 0; k < 2; k++) { /* sg_base_at, from the tile's base on: at most two slides inside a tile */
+        const uint64_t end = (uint64_t)base + 2ull * ZD_TILE;
+        const uint32_t data_end = end < n ? (uint32_t)end : n;
+        const int slide = (uint64_t)p + ZD_MIN_LOOKAHEAD > data_end && p - base >= ZD_TILE + ZD_MAX_DIST;
+        base += slide ? ZD_TILE : 0u;
+    }
+    const uint32_t floor_pos = p - base > ZD_MAX_DIST ? p - ZD_MAX_DIST : base;
+    const uint32_t *runA = job.sorted + (uint64_t)(p >> 15) * ZD_TILE;
+    /* the chain head may lie at exactly MAX_DIST (:2027-2028), later links may not (:1512) */
+    const uint32_t q0 = tileA + (runA[mt_slot(rk, hb, nA, 0u)] & ZD_TILE_MASK) - (nA ? 0u : ZD_TILE);
+    if (!(q0 > base && p - q0 <= ZD_MAX_DIST))
+        return MT_NONE | MT_RLOK; /* longest_match is not called */
+    const uint32_t cap = look < 258u ? look : 258u;
+    const uint32_t nice = job.cfg.nice < look ? job.cfg.nice : look;
     const uint32_t wbase = job.start - ZD_TILE;
     const uint8_t *win = lds->win;
-    MtWave ws;
-    FOR_LANES { LV(ws.st) = MT_S_NEW; }
-    for (;;) {
-        /* ---- up to MT_WALK entries of the chain (asked for in an earlier round) ---- */
-        for (uint32_t t = 0; t < MT_WALK; t++) {
-            FOR_LANES
-            {
-                if (LV(ws.st) == MT_S_WALK) {
-                    const uint32_t p = LV(ws.p);
-                    if (LV(ws.hd)) {
-                        /* the chain head may lie at exactly MAX_DIST (:2027-2028), later links may not (:1512) */
-                        const uint32_t mi = p - (c0 - 1u);
-                        const uint32_t nA = lds->mcnt[mi] & 0xffffu;
-                        const uint32_t q0 = (p & ~ZD_TILE_MASK) - (nA ? 0u : ZD_TILE) + (LV(ws.q0) & ZD_TILE_MASK);
-                        LV(ws.q0) = q0;
-                        LV(ws.hd) = 0;
-                        if (!(q0 > LV(ws.base) && p - q0 <= ZD_MAX_DIST))
-                            LV(ws.st) = MT_S_FIN; /* longest_match is not called: the entry stays MT_NONE */
-                    }
-                }
-                if (LV(ws.st) == MT_S_WALK) {
-                    const uint32_t cj = LV(ws.cj), tj = (cj & 0xffffu) + (cj >> 16), v = LV(ws.v), j = LV(ws.j);
-                    if (v >= tj) {
-                        LV(ws.st) = MT_S_FIN; /* no candidate longer than b */
-                    } else {
-                        const uint32_t p = LV(ws.p);
-                        const uint32_t k = v & 3u;
-                        const uint32_t qj = k == 0u ? LV(ws.cur).q0 : k == 1u ? LV(ws.cur).q1 : k == 2u ? LV(ws.cur).q2 : LV(ws.cur).q3;
-                        LV(ws.v) = v + 1u;
-                        if (k == 3u) {
-                            /* the next four are here; the four after them on their way */
-                            LV(ws.cur) = LV(ws.nxt);
-                            if (v + 5u < tj) {
-                                const uint32_t rhj = LV(ws.rhj);
-                                LV(ws.nxt) = mt_block(job, (p + j) & ~ZD_TILE_MASK, rhj & 0xffffu, rhj >> 16,
-                                                      cj & 0xffffu, tj, v + 5u);
-                            }
-                        }
-                        const uint32_t q = qj - j;
-                        const uint32_t base = LV(ws.base);
-                        const uint32_t floor_pos = p - base > ZD_MAX_DIST ? p - ZD_MAX_DIST : base;
-                        if (qj < j) {
-                            LV(ws.st) = MT_S_FIN;
-                        } else if (++LV(ws.looked) > job.cap) {
-                            LV(ws.res) = MT_INCOMPLETE;
-                            LV(ws.nrec) = 0;
-                            LV(ws.st) = MT_S_FIN;
-                        } else if (q >= LV(ws.bnd)) {
-                            /* newer than the last record: seen at an earlier level */
-                        } else if (!(q > floor_pos || q == LV(ws.q0))) {
-                            LV(ws.st) = MT_S_FIN; /* the chain leaves the window (:1512) */
-                        } else {
-                            const uint32_t iq = q - wbase, b = LV(ws.b);
-                            if (((uint32_t)win[iq + b] << 8 | win[iq + b - 1u]) == LV(ws.sb)) {
-                                LV(ws.qp) = q;
-                                LV(ws.st) = MT_S_LCP;
-                            }
-                        }
-                    }
-                }
+    const uint32_t ip = p - wbase;
+
+    uint32_t b = 2u, bnd = p, where = 0, nrec = 0;
+    uint32_t qs = 0xffffffffu; /* where the walk first stands at a level >= 5 */
+    int open = 1;              /* the walk is not known to be over */
+    for (uint32_t step = 0; step < MT_STEPS && open; step++) {
+        /* the shortest of the chains of p, p+1, p+b-3, p+b-2 */
+        uint32_t j = 0, cj = cn, tj = total, rkj = rk, hbj = hb;
+        if (b >= 3u) {
+            const uint32_t jm = b - 2u;
+            const uint32_t o1 = 1u, o2 = jm >= 2u ? jm - 1u : 1u, o3 = jm;
+            const int ok1 = (uint64_t)p + o1 + 3u <= n, ok2 = (uint64_t)p + o2 + 3u <= n, ok3 = (uint64_t)p + o3 + 3u <= n;
+            const uint32_t c1 = job.cnt[ok1 ? p + o1 : p], c2 = job.cnt[ok2 ? p + o2 : p], c3 = job.cnt[ok3 ? p + o3 : p];
+            const uint32_t t1 = ok1 ? (c1 & 0xffffu) + (c1 >> 16) : 0xffffffffu, t2 = ok2 ? (c2 & 0xffffu) + (c2 >> 16) : 0xffffffffu,
+                           t3 = ok3 ? (c3 & 0xffffu) + (c3 >> 16) : 0xffffffffu;
+            if (t1 < tj) {
+                tj = t1, cj = c1, j = o1;
+            }
+            if (t2 < tj) {
+                tj = t2, cj = c2, j = o2;
+            }
+            if (t3 < tj) {
+                tj = t3, cj = c3, j = o3;
+            }
+            if (j) {
+                rkj = job.rank[p + j];
+                hbj = job.hib[p + j];
             }
         }
-        /* ---- the candidate that showed the two bytes: is it longer? ---- */
+        const uint32_t tpos = (p + j) & ~ZD_TILE_MASK;
+        const uint32_t *run = job.sorted + (uint64_t)((p + j) >> 15) * ZD_TILE;
+        const uint32_t nAj = cj & 0xffffu;
+        const uint32_t sb = (uint32_t)win[ip + b] << 8 | win[ip + b - 1u];
+        int found = 0, ended = 0;
+        uint32_t fq = 0, flen = 0;
+        open = 0;
+        const uint32_t lim = tj < job.cap ? tj : job.cap;
+        uint32_t v = 0;
+        /* four entries a trip (asked for together), each looked at with as few branches as it takes:
+         * a wave pays for every branch of every lane */
+        while (v < lim && !(ended | found)) {
+            uint32_t qq[4];
+            for (uint32_t k = 0; k < 4u; k++) {
+                const uint32_t vk = v + k < tj ? v + k : tj - 1u;
+                qq[k] = tpos + (run[mt_slot(rkj, hbj, nAj, vk)] & ZD_TILE_MASK) - (vk < nAj ? 0u : ZD_TILE);
+            }
+            for (uint32_t k = 0; k < 4u; k++) {
+                const uint32_t qj = qq[k], q = qj - j;
+                const int used = (ended | found) || v + k >= lim;
+                /* the chain leaves the buffer or the window (:1512) */
+                const int gone = !used && (qj < j || (q < bnd && !(q > floor_pos || q == q0)));
+                /* (an entry newer than the last record was seen at an earlier level) */
+                const int cand = !used && !gone && q < bnd;
+                const uint32_t iq = cand ? q - wbase : ip;
+                const uint32_t two = (uint32_t)win[iq + b] << 8 | win[iq + b - 1u];
+                if (cand && two == sb) {
+                    const uint32_t len = mt_lcp(win, iq, ip, cap);
+                    if (len > b) {
+                        found = 1;
+                        fq = q;
+                        flen = len;
+                    }
+                }
+                ended |= gone;
+            }
+            v += 4u;
+        }
+        if (found) {
+            nrec++;
+            b = flen;
+            where = fq;
+            bnd = fq;
+            open = b < nice;
+            if (open && qs == 0xffffffffu && b >= 5u)
+                qs = fq;
+        } else if (!ended && lim < tj) {
+            return MT_INCOMPLETE; /* more of this chain than a lane looks at */
+        }
+    }
+    if (open)
+        return MT_INCOMPLETE; /* more records than a lane follows */
+    uint32_t res = MT_NONE | MT_RLOK;
+    if (nrec != 0) {
+        /* Could the chain budget have ended the walk before its last record?  It is charged by the
+         * records, and by candidates that pass the pre-check without being longer: none while
+         * best_len <= 4 (see the top of the file), so at most as many as p's own chain has entries
+         * between the first record at a level >= 5 and the last record. */
+        uint32_t newer = 0, between = 0;
+        if (where != q0) {
+            const uint32_t r1 = job.rank[where];
+            newer = (where >> 15) == (p >> 15) ? rk - 1u - r1 : nA + (hb - r1);
+            if (qs != 0xffffffffu && qs != where) {
+                const uint32_t r0 = job.rank[qs];
+                between = newer - ((qs >> 15) == (p >> 15) ? rk - 1u - r0 : nA + (hb - r0)) - 1u;
+            }
+        }
+        uint32_t len = b < look ? b : look;
+        if (len <= 5u) { /* :2038-2047 */
+            if (job.strategy == 1u)
+                len = 2;
+            else if (len == 3u && p - where > ZD_TOO_FAR)
+                len = 2;
+        }
+        res = len <= 2u ? MT_NONE : MT_PACK(len, p - where);
+        if (nrec + between >= job.cfg.chain)
+            res = MT_INCOMPLETE;
+        else if (nrec + newer < ((uint32_t)job.cfg.chain >> 2))
+            res |= MT_RLOK; /* the walk from any longer prev_length ends at the same record, whatever passes on its way */
+    }
+    return res;
+}
+
+/* the tile's entries, a lane per position */
+DEV void mt_phase_search(const MtJob &job, const MtLds *lds, int w, uint32_t base0)
+{
+    const uint32_t left = job.n - job.start;
+    const uint32_t m = left < ZD_TILE ? left : ZD_TILE;
+    for (uint32_t i0 = (uint32_t)w * WAVE; i0 < m; i0 += MT_WAVES * WAVE) {
         FOR_LANES
         {
-            if (LV(ws.st) == MT_S_LCP) {
-                const uint32_t p = LV(ws.p), q = LV(ws.qp), look = n - p;
-                const uint32_t cap = look < 258u ? look : 258u;
-                const uint32_t len = mt_lcp(win, q - wbase, p - wbase, cap);
-                LV(ws.st) = MT_S_WALK;
-                if (len > LV(ws.b)) {
-                    const uint32_t nice = job.cfg.nice < look ? job.cfg.nice : look;
-                    LV(ws.nrec)++;
-                    LV(ws.b) = len;
-                    LV(ws.where) = q;
-                    LV(ws.bnd) = q;
-                    LV(ws.st) = len >= nice ? MT_S_FIN : MT_S_PICK;
-                    if (LV(ws.qs) == 0xffffffffu && len >= 5u && len < nice)
-                        LV(ws.qs) = q;
-                }
-            }
-        }
-        /* ---- the entry: written with what the block below asked for in the round before ---- */
-        FOR_LANES
-        {
-            if (LV(ws.st) == MT_S_FIN2) {
-                const uint32_t p = LV(ws.p), b0 = LV(ws.b0), idx = LV(ws.idx);
-                uint32_t res = LV(ws.res);
-                if (LV(ws.nrec) != 0) {
-                    const uint32_t where = LV(ws.where), look = n - p, b = LV(ws.b);
-                    /* Could the chain budget have ended the walk before its last record?  It is charged
-                     * by the records, and by candidates that pass the pre-check without being longer:
-                     * none while best_len <= 4 (see the top of the file), so at most as many as p's own
-                     * chain has entries between the first record at a level >= 5 and the last record. */
-                    const uint32_t mi = p - (c0 - 1u);
-                    const uint32_t cn = lds->mcnt[mi], rh = lds->mrh[mi];
-                    const uint32_t qs = LV(ws.sb); /* (the position; its rank is in ws.qs) */
-                    const uint32_t r1 = LV(ws.qp), r0 = LV(ws.qs);
-                    const uint32_t newer = (where >> 15) == (p >> 15) ? (rh & 0xffffu) - 1u - r1 : (cn & 0xffffu) + ((rh >> 16) - r1);
-                    uint32_t between = 0;
-                    if (qs == p)
-                        between = newer;
-                    else if (qs != 0xffffffffu && qs != where)
-                        between = newer - ((qs >> 15) == (p >> 15) ? (rh & 0xffffu) - 1u - r0 : (cn & 0xffffu) + ((rh >> 16) - r0)) - 1u;
-                    const uint32_t charged = LV(ws.nrec) + between;
-                    const uint32_t budget = b0 >= job.cfg.good ? (uint32_t)job.cfg.chain >> 2 : job.cfg.chain;
-                    uint32_t len = b < look ? b : look;
-                    if (len <= 5u) { /* :2038-2047 */
-                        if (job.strategy == 1u)
-                            len = 2;
-                        else if (len == 3u && p - where > ZD_TOO_FAR)
-                            len = 2;
-                    }
-                    res = len <= b0 ? MT_NONE : MT_PACK(len, p - where);
-                    if (charged >= budget)
-                        res = MT_INCOMPLETE;
-                    else if (LV(ws.nrec) + newer < ((uint32_t)job.cfg.chain >> 2))
-                        res |= MT_RLOK; /* the walk from any longer prev_length ends at the same record, whatever passes on its way */
-                } else if (!(res & MT_INCOMPLETE)) {
-                    res |= MT_RLOK; /* no match at all: none longer than anything either */
-                }
-                mt_store(job, lds, kind, c, npos, idx, p, res);
-                LV(ws.st) = MT_S_NEW;
-            }
-        }
-        FOR_LANES
-        {
-            if (LV(ws.st) == MT_S_FIN) {
-                if (LV(ws.nrec) != 0) {
-                    const uint32_t qs = LV(ws.qs), p = LV(ws.p);
-                    LV(ws.qp) = job.rank[LV(ws.where)];
-                    LV(ws.sb) = qs;
-                    if (qs != 0xffffffffu && qs != p)
-                        LV(ws.qs) = job.rank[qs];
-                }
-                LV(ws.st) = MT_S_FIN2;
-            }
-        }
-        /* ---- a position off the queue ---- */
-        FOR_LANES
-        {
-            while (LV(ws.st) == MT_S_NEW) {
-                const uint32_t idx = LDS_FETCH_ADD_U32(&lds->queue[kind], 1u);
-                if (idx >= nitems) {
-                    LV(ws.st) = MT_S_IDLE;
-                    break;
-                }
-                const uint32_t p = idx < npos ? c0 + idx : job.start - 1u;
-                uint32_t b0 = 2u, res = MT_NONE | MT_RLOK;
-                int search = 1;
-                if (kind != 0u) {
-                    const uint32_t key = idx ? lds->key[c & 1u][idx] : lds->key[(c & 1u) ^ 1u][MT_CHUNK];
-                    const uint32_t own = lds->key[c & 1u][1u + idx];
-                    b0 = key & 0x1ffu;
-                    if (own & MT_K_RLOK)
-                        continue; /* r2[p] answers: rl[p] is not read */
-                    if (key & MT_K_INC) {
-                        res = MT_INCOMPLETE;
-                        search = 0;
-                    } else if (b0 < 3u) {
-                        search = 0;
-                    }
-                }
-                /* :2027: three bytes ahead, and the previous match not good enough already */
-                if ((uint64_t)p + 3u > n || b0 >= job.cfg.lazy)
-                    search = 0;
-                if (search) {
-                    const uint32_t mi = p - (c0 - 1u);
-                    const uint32_t cn = lds->mcnt[mi], rh = lds->mrh[mi];
-                    const uint32_t nA = cn & 0xffffu, total = nA + (cn >> 16);
-                    const uint32_t look = n - p; /* what matters of it: fill_window keeps MIN_LOOKAHEAD bytes ahead until the input ends */
-                    search = total != 0 && b0 < look;
-                    if (search) {
-                        uint32_t base = idx < npos ? base0 : (base0 >= ZD_TILE ? base0 - ZD_TILE : 0u);
-                        for (;;) { /* sg_base_at, from the tile's base on (at most two steps) */
-                            const uint64_t end = (uint64_t)base + 2ull * ZD_TILE;
-                            const uint32_t data_end = end < n ? (uint32_t)end : n;
-                            if ((uint64_t)p + ZD_MIN_LOOKAHEAD > data_end && p - base >= ZD_TILE + ZD_MAX_DIST)
-                                base += ZD_TILE;
-                            else
-                                break;
-                        }
-                        /* the head of p's chain: looked at when the walk begins */
-                        const uint32_t *run = job.sorted + (uint64_t)(p >> 15) * ZD_TILE;
-                        LV(ws.q0) = nA ? run[(rh & 0xffffu) - 1u] : (run - ZD_TILE)[rh >> 16];
-                        LV(ws.hd) = 1;
-                        LV(ws.base) = base;
-                        LV(ws.idx) = idx;
-                        LV(ws.p) = p;
-                        LV(ws.b0) = b0;
-                        LV(ws.res) = MT_NONE;
-                        LV(ws.nrec) = 0;
-                        LV(ws.b) = b0;
-                        LV(ws.bnd) = p;
-                        LV(ws.where) = 0;
-                        LV(ws.qs) = b0 >= 5u ? p : 0xffffffffu;
-                        LV(ws.looked) = 0;
-                        LV(ws.st) = MT_S_PICK;
-                    }
-                }
-                if (!search)
-                    mt_store(job, lds, kind, c, npos, idx, p, res);
-            }
-        }
-        {
-            LANEVAR(int, busy);
-            FOR_LANES { LV(busy) = LV(ws.st) != MT_S_IDLE; }
-            if (BALLOT(busy) == 0)
-                break;
-        }
-        /* ---- the shortest of the chains of p, p+1, p+b-3, p+b-2 ---- */
-        FOR_LANES
-        {
-            if (LV(ws.st) == MT_S_PICK) {
-                const uint32_t p = LV(ws.p), b = LV(ws.b);
-                const uint32_t mi = p - (c0 - 1u);
-                uint32_t j = 0, cj = lds->mcnt[mi];
-                uint32_t tj = (cj & 0xffffu) + (cj >> 16);
-                if (b >= 3u) {
-                    const uint32_t jm = b - 2u;
-                    const uint32_t o1 = 1u, o2 = jm >= 2u ? jm - 1u : 1u, o3 = jm;
-                    const uint32_t c1 = lds->mcnt[mi + o1], c2 = lds->mcnt[mi + o2], c3 = lds->mcnt[mi + o3];
-                    /* (a position without three bytes ahead has no chain: staged as empty, skipped here) */
-                    const uint32_t t1 = (uint64_t)p + o1 + 3u <= n ? (c1 & 0xffffu) + (c1 >> 16) : 0xffffffffu;
-                    const uint32_t t2 = (uint64_t)p + o2 + 3u <= n ? (c2 & 0xffffu) + (c2 >> 16) : 0xffffffffu;
-                    const uint32_t t3 = (uint64_t)p + o3 + 3u <= n ? (c3 & 0xffffu) + (c3 >> 16) : 0xffffffffu;
-                    if (t1 < tj) {
-                        tj = t1, cj = c1, j = o1;
-                    }
-                    if (t2 < tj) {
-                        tj = t2, cj = c2, j = o2;
-                    }
-                    if (t3 < tj) {
-                        tj = t3, cj = c3, j = o3;
-                    }
-                }
-                const uint32_t rhj = lds->mrh[mi + j];
-                const uint32_t ip = p - wbase;
-                LV(ws.j) = j;
-                LV(ws.cj) = cj;
-                LV(ws.rhj) = rhj;
-                LV(ws.v) = 0;
-                LV(ws.sb) = (uint32_t)win[ip + b] << 8 | win[ip + b - 1u];
-                const uint32_t tpos = (p + j) & ~ZD_TILE_MASK;
-                LV(ws.cur) = mt_block(job, tpos, rhj & 0xffffu, rhj >> 16, cj & 0xffffu, tj, 0u);
-                if (4u < tj)
-                    LV(ws.nxt) = mt_block(job, tpos, rhj & 0xffffu, rhj >> 16, cj & 0xffffu, tj, 4u);
-                LV(ws.st) = MT_S_WALK;
-            }
+            const uint32_t i = i0 + (uint32_t)LANE;
+            if (i < m)
+                job.r2[job.start + i] = mt_search(job, lds, job.start + i, base0);
         }
     }
 }

@@ -85,6 +85,15 @@ static inline T emu_sum(const T *in)
     return run;
 }
 #define WAVE_SUM(in) emu_sum(in)
+template <typename T>
+static inline T emu_min(const T *in)
+{
+    T m = in[0];
+    for (int i = 1; i < WAVE; i++)
+        m = in[i] < m ? in[i] : m;
+    return m;
+}
+#define WAVE_MIN_U32(in) emu_min(in) /* the smallest value over the lanes (the same in every lane) */
 
 static inline uint32_t ld_u32(const uint8_t *p)
 {
@@ -184,6 +193,17 @@ DEV uint64_t wave_sum_u64(uint64_t v)
     return v;
 }
 #define WAVE_SUM(in) wave_sum_u64(in)
+
+DEV uint32_t wave_min_u32(uint32_t v)
+{
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) {
+        const uint32_t o = (uint32_t)__shfl_xor((int)v, d);
+        v = o < v ? o : v;
+    }
+    return (uint32_t)__builtin_amdgcn_readfirstlane((int)v);
+}
+#define WAVE_MIN_U32(in) wave_min_u32(in)
 
 DEV uint32_t ld_u32(const uint8_t *p)
 {

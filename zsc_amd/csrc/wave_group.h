@@ -28,6 +28,7 @@
 #undef GREADLANE
 #undef GUNI
 #undef GSUM64
+#undef GMIN_U32
 
 #ifndef ZSC_GROUP
 #define ZSC_GROUP 64
@@ -44,6 +45,7 @@
 #define GREADLANE(name, l) READLANE(name, l)
 #define GUNI(x) UNI(x)
 #define GSUM64(in) WAVE_SUM(in)
+#define GMIN_U32(in) WAVE_MIN_U32(in)
 #else
 #define GRP ZSC_GROUP
 #define GROUPS_PER_WAVE (64 / ZSC_GROUP)
@@ -55,6 +57,7 @@
 #define GREADLANE(name, l) ((decltype(name))__shfl((int)(name), (int)(threadIdx.x & (64 - ZSC_GROUP)) + (int)(l)))
 #define GUNI(x) (x)
 #define GSUM64(in) group_sum_u64(in)
+#define GMIN_U32(in) group_min_u32(in)
 #ifndef ZSC_GROUP_SUM_DEFINED
 #define ZSC_GROUP_SUM_DEFINED
 DEV uint64_t group_sum_u64(uint64_t v)
@@ -62,6 +65,15 @@ DEV uint64_t group_sum_u64(uint64_t v)
 #pragma unroll
     for (int d = ZSC_GROUP / 2; d >= 1; d >>= 1) /* (every group code in one source uses the same width) */
         v += __shfl_xor(v, d);
+    return v;
+}
+DEV uint32_t group_min_u32(uint32_t v)
+{
+#pragma unroll
+    for (int d = ZSC_GROUP / 2; d >= 1; d >>= 1) {
+        const uint32_t o = (uint32_t)__shfl_xor((int)v, d);
+        v = o < v ? o : v;
+    }
     return v;
 }
 #endif

@@ -216,7 +216,7 @@ __global__ __launch_bounds__(MT_WAVES * 64) MT_ATTR void k_match_table(
     const uint8_t *__restrict__ in, const ZdBuf *__restrict__ bufs,
     const uint32_t *__restrict__ tile_owner, const uint32_t *__restrict__ sorted,
     const uint16_t *__restrict__ rank, const uint16_t *__restrict__ hib,
-    const uint32_t *__restrict__ cnt, uint32_t *__restrict__ r2, uint32_t *__restrict__ rl,
+    const uint32_t *__restrict__ cnt, uint32_t *__restrict__ r2,
     const ZdLevel cfg, uint32_t min_len, uint32_t cap, uint32_t ntiles)
 {
     __shared__ MtLds lds;
@@ -236,7 +236,6 @@ __global__ __launch_bounds__(MT_WAVES * 64) MT_ATTR void k_match_table(
     job.hib = hib + buf.rank_off;
     job.cnt = cnt + buf.rank_off;
     job.r2 = r2 + buf.rank_off;
-    job.rl = rl + buf.rank_off;
     job.cfg = cfg;
     job.cfg.wsize = ZD_TILE;
     job.cfg.max_dist = ZD_MAX_DIST;
@@ -248,16 +247,7 @@ __global__ __launch_bounds__(MT_WAVES * 64) MT_ATTR void k_match_table(
     mt_phase_load(job, &lds, w);
     __syncthreads();
     const uint32_t base0 = sg_base(job.cfg, job.start, job.n);
-    const uint32_t left = job.n - job.start;
-    const uint32_t nchunk = ((left < ZD_TILE ? left : ZD_TILE) + MT_CHUNK - 1u) / MT_CHUNK;
-    for (uint32_t c = 0; c < nchunk; c++) {
-        mt_phase_stage(job, &lds, w, c);
-        __syncthreads();
-        mt_phase_search(job, &lds, w, c, 0u, base0);
-        __syncthreads();
-        mt_phase_search(job, &lds, w, c, 1u, base0);
-        __syncthreads();
-    }
+    mt_phase_search(job, &lds, w, base0);
 }
 
 /* kernel 2: one wavefront per buffer, longest buffers first.  L picks the LDS ring
@@ -289,7 +279,8 @@ __global__ __launch_bounds__(64) void k_parse(const uint8_t *__restrict__ in,
     job.rank = rank + buf.rank_off;
     job.hib = hib + buf.rank_off;
     job.cnt = nullptr;
-    job.r2 = job.rl = nullptr;
+    job.r2 = nullptr;
+    job.stair_min = 0xffffffffu;
     job.syms = syms + buf.sym_off;
     job.blocks = recs + buf.blk0;
     job.out = pout + b;
@@ -313,15 +304,14 @@ __global__ __launch_bounds__(SG_W * 64, SG_MIN_WAVES) void k_parse_seg(const uin
                                                          const uint16_t *__restrict__ hib,
                                                          const uint32_t *__restrict__ cnt,
                                                          const uint32_t *__restrict__ r2,
-                                                         const uint32_t *__restrict__ rl,
                                                          uint32_t *__restrict__ syms,
                                                          ZdBlockRec *__restrict__ recs,
                                                          ZdParseOut *__restrict__ pout,
                                                          uint32_t *__restrict__ seg_tok,
                                                          uint16_t *__restrict__ seg_sidx,
                                                          const ZdSched *__restrict__ sched,
-                                                         const ZdLevel cfg, uint32_t first,
-                                                         uint32_t nbuf)
+                                                         const ZdLevel cfg, uint32_t stair_min,
+                                                         uint32_t first, uint32_t nbuf)
 {
     __shared__ SgLds lds;
     if (blockIdx.x >= nbuf)
@@ -338,7 +328,7 @@ __global__ __launch_bounds__(SG_W * 64, SG_MIN_WAVES) void k_parse_seg(const uin
     job.cnt = cnt + buf.rank_off;
     /* the match table covers plain buffers (match_table.h); a run with joints is searched as before */
     job.r2 = r2 && buf.sched_n == 0 ? r2 + buf.rank_off : nullptr;
-    job.rl = rl && buf.sched_n == 0 ? rl + buf.rank_off : nullptr;
+    job.stair_min = stair_min;
     job.syms = syms + buf.sym_off;
     job.blocks = recs + buf.blk0;
     job.out = pout + b;
@@ -431,7 +421,8 @@ __global__ __launch_bounds__(64) void k_parse_simple(const uint8_t *__restrict__
     job.rank = nullptr;
     job.hib = nullptr;
     job.cnt = nullptr;
-    job.r2 = job.rl = nullptr;
+    job.r2 = nullptr;
+    job.stair_min = 0xffffffffu;
     job.syms = syms + buf.sym_off;
     job.blocks = recs + buf.blk0;
     job.out = pout + b;
@@ -475,7 +466,8 @@ __global__ __launch_bounds__(64) void k_parse_fast(const uint8_t *__restrict__ i
     job.rank = rank + buf.rank_off;
     job.hib = hib + buf.rank_off;
     job.cnt = nullptr;
-    job.r2 = job.rl = nullptr;
+    job.r2 = nullptr;
+    job.stair_min = 0xffffffffu;
     job.syms = syms + buf.sym_off;
     job.blocks = recs + buf.blk0;
     job.out = pout + b;
@@ -817,10 +809,11 @@ struct zsc_hip_deflate_plan {
     /* scratch shared by all sub-batches (sized for the largest) */
     DevBuf d_sorted, d_tmp_syms, d_rank, d_hib, d_cnt, d_dir, d_recs, d_plans, d_pout;
     DevBuf d_seg_tok, d_seg_sidx; /* per long buffer: token staging of the segmented parser */
-    DevBuf d_r2, d_rl; /* the match table (match_table.h): two entries per input position */
+    DevBuf d_r2; /* the match table (match_table.h): one entry per input position */
     bool use_table = false;
     uint32_t table_min = 0; /* buffers longer than this have a table (those the segmented parser takes) */
     uint32_t table_cap = MT_CAP;
+    uint32_t stair_min = SG_STAIR_MIN; /* chains at least this long are searched as a staircase (lz_parse_seg.h) */
     DevBuf d_sched;               /* joints of runs of sections (sections.h) */
     bool use_seg = true;
     DevBuf d_res; /* one ZdResult per buffer of the whole plan */
@@ -1166,17 +1159,21 @@ static ZlibReturn plan_create(zsc_hip_deflate_plan **plan_out, U32 count, const 
               pl->d_res.ensure((uint64_t)std::max(1u, count) * sizeof(ZdResult));
     /* the match table: levels 4-9 with the default window and hash size, for the buffers the
      * segmented parser takes; the match-finding strategies (default, filtered, fixed) share it */
-    pl->use_table = getenv("ZSC_HIP_NO_TABLE") == nullptr && pl->use_seg && max_seg != 0 && wbits == 15 &&
+    /* Off unless asked for (ZSC_HIP_TABLE=1): measured on the MI355X the table
+     * kernel costs what the hops it buys save -- 23 ms per 403 MB of text for 40 % of the loop tops. */
+    pl->use_table = getenv("ZSC_HIP_TABLE") != nullptr && pl->use_seg && max_seg != 0 && wbits == 15 &&
                     mem_level == 8 && strategy != Z_HUFFMAN_ONLY && strategy != Z_RLE;
+    if (const char *e = getenv("ZSC_HIP_STAIR_MIN")) /* (debugging / tuning aid) */
+        pl->stair_min = (uint32_t)atoi(e);
     if (const char *e = getenv("ZSC_HIP_TABLE_CAP")) /* (debugging / tuning aid) */
         pl->table_cap = (uint32_t)atoi(e);
     if (ok && pl->use_table)
-        ok = pl->d_r2.ensure(max_rank_span * 4) && pl->d_rl.ensure(max_rank_span * 4);
+        ok = pl->d_r2.ensure(max_rank_span * 4);
     if (!ok) {
         zsc_hip_deflate_plan_destroy(pl);
         return Z_MEM_ERROR;
     }
-    pl->scratch_bytes += pl->d_r2.bytes + pl->d_rl.bytes;
+    pl->scratch_bytes += pl->d_r2.bytes;
     pl->scratch_bytes += pl->d_sorted.bytes + pl->d_tmp_syms.bytes + pl->d_rank.bytes + pl->d_hib.bytes + pl->d_cnt.bytes +
                          pl->d_dir.bytes + pl->d_recs.bytes + pl->d_plans.bytes +
                          pl->d_pout.bytes + pl->d_res.bytes;
@@ -1256,7 +1253,7 @@ extern "C" ZlibReturn zsc_hip_deflate_plan_run(zsc_hip_deflate_plan *pl, const v
                 hipLaunchKernelGGL(k_match_table, dim3(sb.ntiles), dim3(MT_WAVES * 64), 0, st, in, bufs,
                                    (const uint32_t *)sb.d_tile_owner.p, (const uint32_t *)sorted,
                                    (const uint16_t *)rank, (const uint16_t *)hib, (const uint32_t *)cnt,
-                                   (uint32_t *)pl->d_r2.p, (uint32_t *)pl->d_rl.p, cfg, pl->table_min,
+                                   (uint32_t *)pl->d_r2.p, cfg, pl->table_min,
                                    pl->table_cap, sb.ntiles);
         }
         mark();
@@ -1277,10 +1274,9 @@ extern "C" ZlibReturn zsc_hip_deflate_plan_run(zsc_hip_deflate_plan *pl, const v
                                    (const uint32_t *)sb.d_order.p, (const uint32_t *)sorted,
                                    (const uint16_t *)rank, (const uint16_t *)hib,
                                    (const uint32_t *)cnt,
-                                   pl->use_table ? (const uint32_t *)pl->d_r2.p : nullptr,
-                                   pl->use_table ? (const uint32_t *)pl->d_rl.p : nullptr, tmp_syms, recs,
+                                   pl->use_table ? (const uint32_t *)pl->d_r2.p : nullptr,                                    tmp_syms, recs,
                                    pout, (uint32_t *)pl->d_seg_tok.p, (uint16_t *)pl->d_seg_sidx.p,
-                                   (const ZdSched *)pl->d_sched.p, cfg, 0u, sb.cseg);
+                                   (const ZdSched *)pl->d_sched.p, cfg, pl->stair_min, 0u, sb.cseg);
             }
             if (pl->d_sched.p) { /* runs with joints: the parsers keep a hole map (lz_parse.h) */
                 ZSC_LAUNCH_PARSE(LzLdsJ, sb.cseg, sb.c36 - sb.cseg);
@@ -1405,7 +1401,6 @@ extern "C" void zsc_hip_deflate_plan_destroy(zsc_hip_deflate_plan *pl)
     pl->d_seg_tok.release();
     pl->d_seg_sidx.release();
     pl->d_r2.release();
-    pl->d_rl.release();
     pl->d_sched.release();
     pl->d_dir.release();
     pl->d_recs.release();
