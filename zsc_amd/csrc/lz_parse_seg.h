@@ -849,11 +849,16 @@ DEV void sg_parse_segment(const LzJob &job, SgLds *lds, const SgScratch &scr, ui
                         const int32_t hiAj = (int32_t)(rhj & 0xffffu) - 1, hiBj = (int32_t)(rhj >> 16);
                         const uint32_t tileJ = (p + j) & ~ZD_TILE_MASK;
                         const uint32_t *runJ = job.sorted + (uint64_t)((p + j) >> 15) * ZD_TILE;
-                        if (best <= 3u) /* the two bytes are among the four read at p */
-                            sb = (s0123 >> (8u * (best - 1u))) & 0xffffu;
-                        else {
-                            SG_PEEK32(p + best - 1, sb);
-                            sb &= 0xffffu;
+                        /* A candidate longer than best matches ALL of p's bytes 0 .. best: the four that end
+                         * at best (the reference's pre-check looks at the last two of them), the first four,
+                         * and four in the middle are looked at before the long compare is spent on it.
+                         * (best == 2: the first three bytes are the whole test.) */
+                        uint32_t sb4 = 0, smid = 0;
+                        const uint32_t omid = best >= 8u ? best / 2u : 0u;
+                        if (best >= 3u) {
+                            SG_PEEK32(p + best - 3u, sb4);
+                            if (omid)
+                                SG_PEEK32(p + omid, smid);
                         }
                         int found = 0, gone = 0;
                         for (uint32_t bb = 0; bb * GRP < totj && !found && !gone; bb++) {
@@ -885,13 +890,20 @@ DEV void sg_parse_segment(const LzJob &job, SgLds *lds, const SgScratch &scr, ui
                                 /* (an entry newer than the last step's candidate was seen at an earlier level) */
                                 const int live = have && !g && q < bnd;
                                 const uint32_t r0 = live ? lz_ridx<L>(st, q) : 0u;
-                                const uint32_t r1 = live ? lz_ridx<L>(st, q + best - 1) : 0u;
                                 const uint32_t w0 = lds_u32(lds->ring, r0);
-                                const uint32_t g1 = lds_u32(lds->ring, r1) & 0xffffu;
+                                int ok = live && ((w0 ^ s0123) & 0xffffffu) == 0u;
+                                if (best >= 3u) {
+                                    const uint32_t r1 = live ? lz_ridx<L>(st, q + best - 3u) : 0u;
+                                    ok = ok && w0 == s0123 && lds_u32(lds->ring, r1) == sb4;
+                                    if (omid) {
+                                        const uint32_t r2 = live ? lz_ridx<L>(st, q + omid) : 0u;
+                                        ok = ok && lds_u32(lds->ring, r2) == smid;
+                                    }
+                                }
                                 LV(_q) = q;
                                 LV(_w0) = w0;
                                 LV(_gone) = g;
-                                LV(_pass) = live && g1 == sb && ((w0 ^ s0123) & 0xffffffu) == 0u;
+                                LV(_pass) = ok;
                             }
                             const uint64_t mgone = GBALLOT(_gone);
                             uint64_t todo = GBALLOT(_pass);
