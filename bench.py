@@ -55,6 +55,7 @@ def cpu_baseline(level: int, seconds_budget: float = 20.0):
     except Exception:
         pass
     # a one-GPU box owns a 16-core share of the host (more threads would only oversubscribe it)
+    nproc = cores
     cores = max(1, min(cores, int(os.environ.get("ZSC_BENCH_CPU_THREADS", "16"))))
     kind = "reference" if Reference.available() else "port"
     sets = [corpus.canterbury_like(s) for s in range(2)]
@@ -78,9 +79,43 @@ def cpu_baseline(level: int, seconds_budget: float = 20.0):
     with ThreadPoolExecutor(max_workers=cores) as ex:
         total = sum(ex.map(worker, range(cores)))
     dt = time.perf_counter() - t0
-    return {"value": round(total / dt / 1e6, 2), "unit": "MB/s", "cores": cores, "kind": kind,
+    return {"value": round(total / dt / 1e6, 2), "unit": "MB/s", "cores": cores, "host_cpus": nproc, "kind": kind,
             "sample": f"{total // set_bytes} Canterbury-like sets ({total / 1e6:.0f} MB) at level "
                       f"{level}, one codec instance per thread, {dt:.1f} s wall"}
+
+
+def cpu_baseline_bufs(bufs, level: int, seconds_budget: float):
+    """The CPU codec on the host cores over a given list of buffers (bounded sample), as cpu_baseline."""
+    from concurrent.futures import ThreadPoolExecutor
+    from oracle.oracle_py import Oracle, Reference
+
+    cores = os.cpu_count() or 1
+    try:
+        cores = len(os.sched_getaffinity(0))
+    except Exception:
+        pass
+    nproc = cores
+    cores = max(1, min(cores, int(os.environ.get("ZSC_BENCH_CPU_THREADS", "16"))))
+    kind = "reference" if Reference.available() else "port"
+
+    def worker(idx: int):
+        codec = Reference() if kind == "reference" else Oracle()
+        done, k = 0, idx
+        t_end = time.perf_counter() + seconds_budget
+        while time.perf_counter() < t_end:
+            b = bufs[k % len(bufs)]
+            assert codec.compress(b, level)[0] == 0
+            done += len(b)
+            k += cores
+        return done
+
+    t0 = time.perf_counter()
+    with ThreadPoolExecutor(max_workers=cores) as ex:
+        total = sum(ex.map(worker, range(cores)))
+    dt = time.perf_counter() - t0
+    return {"value": round(total / dt / 1e6, 2), "unit": "MB/s", "cores": cores, "host_cpus": nproc, "kind": kind,
+            "sample": f"{total / 1e6:.0f} MB from the {len(bufs)} distinct buffers at level {level}, one codec "
+                      f"instance per thread, {dt:.1f} s wall"}
 
 
 def cpu_inflate_baseline(streams, outs, seconds_budget: float = 10.0):
@@ -145,17 +180,17 @@ def bench_inflate(dev, stream, nstreams: int, distinct: int, fence, orders=("nei
     all_caps = (sizes * reps)[:nstreams]
     # Two orders of the same batch.  The plan decodes streams longest first, four to a wavefront,
     # so the 512 replicas of a member would sit next to each other and the four streams of a
-    # wavefront would be identical (they never diverge: the best case).  ZSC_HIP_INFLATE_SPREAD
-    # makes neighbours in that order DIFFERENT members of nearly the same length -- what a batch of
+    # wavefront would be identical (they never diverge: the best case).  With an explicit decode
+    # order neighbours are DIFFERENT members of nearly the same length -- what a batch of
     # all-different streams looks like -- and that is the figure reported as `value`.
     results = {}
     for mode in orders:
+        order = None
         if mode == "neighbours_differ" and nstreams % distinct == 0 and nstreams > distinct:
-            os.environ["ZSC_HIP_INFLATE_SPREAD"] = str(distinct)
-        else:
-            os.environ.pop("ZSC_HIP_INFLATE_SPREAD", None)
-        ip = zsc_amd.InflatePlan(all_slens, all_caps, window_bits=31)
-        os.environ.pop("ZSC_HIP_INFLATE_SPREAD", None)
+            by_len = sorted(range(nstreams), key=lambda i: -all_caps[i])  # (stable: the library's own order)
+            r = nstreams // distinct
+            order = [by_len[(k % distinct) * r + k // distinct] for k in range(nstreams)]
+        ip = zsc_amd.InflatePlan(all_slens, all_caps, window_bits=31, decode_order=order)
         # one period of the source layout on the host, replicated on the device
         per_src = ip.src_offsets[distinct] if nstreams > distinct else ip.src_bytes - 64
         per_dst = ip.dst_offsets[distinct] if nstreams > distinct else ip.dst_bytes - 64
@@ -216,11 +251,11 @@ def bench_inflate(dev, stream, nstreams: int, distinct: int, fence, orders=("nei
             "note": "zsc_uncompress_gzip semantics (header, CRC-32 and ISIZE checked), one 16-lane group per "
                     "member (four members per wavefront, taken from one queue), members and outputs resident in "
                     "HBM; all outputs compared with their sources; `value`: neighbours in the decode order are "
-                    "different members (ZSC_HIP_INFLATE_SPREAD)"}
+                    "different members (an explicit decode order, zsc_hip_inflate_plan_create_ordered)"}
     return info, members, bufs
 
 
-def bench_levels_64k(dev, stream, count: int, fence):
+def bench_levels_64k(dev, stream, count: int, fence, cpu: bool = True):
     """BASELINE config 3: count x 64 KiB (random / zero / text) at levels 1, 6, 9."""
     import torch
     import zsc_amd
@@ -259,14 +294,185 @@ def bench_levels_64k(dev, stream, count: int, fence):
             got = bytes(head[plan.out_offsets[k]:plan.out_offsets[k] + lens[k]].numpy())
             ok = ok and got == oracle.compress(bufs[k], level)[1]
         ok = ok and all(lens[i] == lens[i % distinct] for i in range(count))
+        alg = 65536 * count + sum(lens)
+        pk = "parse"
+        achieved = alg / (kt[pk] * 1e-3) / 1e9 if kt[pk] > 0 else 0.0
         out[f"L{level}"] = {"MB_per_s_in": round(65536 * count / wall / 1e6, 2), "ms_per_step": round(wall * 1e3, 3),
                             "compressed_bytes": sum(lens), "all_ok": bool(ok),
+                            "roofline": {"bound": "hbm", "kernel": "k_parse_fast" if level < 4 else "k_parse_seg",
+                                         "achieved": round(achieved, 3), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                                         "frac": round(achieved / HBM_PEAK_GBS, 6), "kernel_ms": round(kt[pk], 3),
+                                         "algorithmic_bytes_per_launch": alg, "traffic": None},
                             "kernel_ms": {k: round(v, 3) for k, v in kt.items()}}
+        if cpu:
+            out[f"L{level}"]["cpu_baseline"] = cpu_baseline_bufs(bufs, level, 4.0)
         plan.close()
         del d_in, d_out
     return {"metric": "deflate uncompressed MB/s in, 64 KiB random / zero / text buffers (BASELINE config 3)",
             "buffers": count, "input_bytes": 65536 * count, "levels": out,
             "note": f"{distinct} distinct buffers replicated; every distinct stream compared with the oracle"}
+
+
+# the reference's own published totals for the Canterbury corpus (2 810 784 B) compressed by
+# zsc_compress with max_block_len 100 000: /root/reference/README.md:170-179, Raspberry Pi 4
+README_TOTALS = {0: 2811285, 1: 842979, 2: 821886, 3: 809844, 4: 768442, 5: 747916, 6: 744167, 7: 742155,
+                 8: 738951, 9: 738674}
+
+
+def bench_corpus_dir(path: str):
+    """if the REAL Canterbury files are there, compress them as the reference's performance
+    test does (zsc_compress, max_block_len 100 000, test/zlib_gtest.cpp:2406) and put the totals next to
+    the reference's published ones.  Host pointers through zsc_hip_compress_sections_batch; untimed."""
+    import zsc_amd
+    from zsc_amd import corpus
+    from oracle.oracle_py import Oracle
+
+    names = [n for n, _, _ in corpus.CANTERBURY_LIKE]
+    found = [n for n in names if os.path.isfile(os.path.join(path, n))]
+    info = {"dir": path, "files_found": len(found), "of": len(names)}
+    if not found:
+        info["note"] = "none of the 11 Canterbury files is in this directory"
+        return info
+    bufs = [open(os.path.join(path, n), "rb").read() for n in found]
+    info["input_bytes"] = sum(len(b) for b in bufs)
+    oracle = Oracle()
+    levels = {}
+    for level in (1, 6, 9):
+        rc, outs, stats = zsc_amd.compress_sections_batch(bufs, [100000] * len(bufs), level=level)
+        ok = rc == 0 and all(x == 0 for x in stats)
+        for b, o in zip(bufs, outs):  # the checker: the oracle's call-by-call restatement of the wrapper
+            cap = zsc_amd.compress_get_max_output_size2(len(b), 100000, level)[1]
+            want = oracle.compress(b, level, max_block_len=100000, dest_cap=cap)
+            ok = ok and (want[0], want[1]) == (0, o)
+        total = sum(len(o) for o in outs)
+        levels[f"L{level}"] = {"compressed_bytes": total, "reference_README_total": README_TOTALS[level],
+                               "equal": total == README_TOTALS[level] if len(found) == len(names) else None,
+                               "streams_equal_oracle": bool(ok)}
+    info["levels"] = levels
+    info["note"] = ("the reference publishes totals for the whole corpus only; `equal` is null when files are "
+                    "missing")
+    return info
+
+
+def run_config5(args, rank, world, local, dev):
+    """BASELINE config 5: a FIXED batch -- args.config5 GiB of 64 KiB random / zero / text buffers at level
+    6 -- cut over the GPUs (strong scaling).  The batch is staged in GPU 0's memory, every other rank gets
+    its byte range point to point and sends its streams back (zsc_amd.sharding); the ranges are
+    contiguous runs of buffers balanced by a cost proxy (sharding.cost_proxy), not by bytes.  One JSON
+    line from rank 0; the scatter / gather times stand beside `value`, which times the steps only."""
+    import torch
+    import torch.distributed as dist
+    import zsc_amd
+    from zsc_amd import corpus, sharding
+    from oracle.oracle_py import Oracle
+
+    count = int(args.config5 * (1 << 30)) // 65536
+    count -= count % 3
+    kinds = ["random", "zero", "text"] * (count // 3)
+    lens = [65536] * count
+    ub, ue = sharding.scatter_assignments(sharding.cost_proxy(lens, kinds), rank, world, device=dev)
+    # every rank learns every range (the root needs them to cut the payload)
+    tbl = torch.zeros(2 * world, dtype=torch.int64, device=dev)
+    tbl[2 * rank], tbl[2 * rank + 1] = ub, ue
+    if world > 1:
+        dist.all_reduce(tbl, op=dist.ReduceOp.SUM)
+    ranges = [(int(tbl[2 * r]), int(tbl[2 * r + 1])) for r in range(world)]
+    mine = ue - ub
+    plan = zsc_amd.DeflatePlan([65536] * mine, level=args.level)
+    stride_in = plan.in_offsets[1] if mine > 1 else plan.in_bytes - 64
+    stride_out = plan.out_offsets[1] if mine > 1 else plan.out_bytes - 64
+    distinct = 96
+    bufs = corpus.mix64k(distinct, 5)  # buffer i of the batch is bufs[i % 96]: kinds repeat with period 3
+    full = None
+    if rank == 0:
+        host = torch.zeros(distinct * stride_in, dtype=torch.uint8)
+        for i, b in enumerate(bufs):
+            host[i * stride_in:i * stride_in + 65536] = torch.frombuffer(bytearray(b), dtype=torch.uint8)
+        reps = (count + distinct - 1) // distinct
+        full = host.to(dev).repeat(reps)[:count * stride_in]
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    t0 = time.perf_counter()
+    d_in_body = sharding.scatter_payload(full, [(b * stride_in, e * stride_in) for b, e in ranges], rank, world,
+                                         device=dev)
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    scatter_ms = (time.perf_counter() - t0) * 1e3
+    d_in = torch.zeros(plan.in_bytes, dtype=torch.uint8, device=dev)
+    d_in[:mine * stride_in] = d_in_body
+    del d_in_body, full
+    d_out = torch.empty(plan.out_bytes, dtype=torch.uint8, device=dev)
+    stream = torch.cuda.current_stream().cuda_stream
+
+    def fence():
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        plan.run(d_in.data_ptr(), d_out.data_ptr(), stream)
+    fence()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        plan.run(d_in.data_ptr(), d_out.data_ptr(), stream)
+    fence()
+    elapsed = time.perf_counter() - t0
+    olens, stats = plan.results()
+    if any(x != 0 for x in stats):
+        raise SystemExit(f"rank {rank}: {sum(1 for x in stats if x)} buffers failed")
+    t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+    if world > 1:
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    elapsed = float(t[0])
+    # parity: this rank's first 96 buffers against the oracle, the rest against their first copy
+    oracle = Oracle()
+    ok = True
+    nchk = min(distinct, mine)
+    head = d_out[:nchk * stride_out].cpu()
+    for k in range(nchk):
+        got = bytes(head[k * stride_out:k * stride_out + olens[k]].numpy())
+        ok = ok and got == oracle.compress(bufs[(ub + k) % distinct], args.level)[1]
+    ok = ok and all(olens[i] == olens[i % distinct] for i in range(mine) if i % distinct < nchk)
+    t0 = time.perf_counter()
+    out_ranges = [(b * stride_out, e * stride_out) for b, e in ranges]
+    gathered = sharding.gather_payload(d_out[:mine * stride_out], out_ranges, rank, world, device=dev)
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    gather_ms = (time.perf_counter() - t0) * 1e3
+    okt = torch.tensor([1 if ok else 0], dtype=torch.int64, device=dev)
+    szt = torch.tensor([sum(olens)], dtype=torch.int64, device=dev)
+    if world > 1:
+        dist.all_reduce(okt, op=dist.ReduceOp.MIN)
+        dist.all_reduce(szt, op=dist.ReduceOp.SUM)
+    if rank == 0:
+        total_in = 65536 * count
+        line = {"metric": f"deflate level-{args.level} uncompressed MB/s in, {args.config5:g} GiB of 64 KiB random / "
+                          f"zero / text buffers cut over the GPUs (BASELINE config 5)",
+                "value": round(total_in * args.steps / elapsed / 1e6, 2), "unit": "MB/s", "n_gpus": world,
+                "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(elapsed / args.steps * 1e3, 3),
+                "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "u8",
+                "data": "synthetic",
+                "config": {"workload": f"{count} x 64 KiB buffers ({total_in} B), one third random, zero, text "
+                                       f"(96 distinct, replicated), zsc_compress level {args.level}",
+                           "buffers_per_gpu": [e - b for b, e in ranges],
+                           "partition": "contiguous runs of buffers balanced by sharding.cost_proxy (bytes x a "
+                                        "per-class cost from the measured parse rates)",
+                           "parallelism": f"{world} x independent shards; payload staged on GPU 0, scattered and "
+                                          "gathered point to point, outside the timed steps"},
+                "staged_on_root": {"scatter_ms": round(scatter_ms, 3), "gather_ms": round(gather_ms, 3),
+                                   "input_bytes": count * stride_in, "output_bytes": count * stride_out},
+                "compressed_bytes_total": int(szt[0]), "all_ok": bool(int(okt[0]) == 1),
+                "device": zsc_amd.device_info()}
+        print(json.dumps(line), flush=True)
+    plan.close()
+    del gathered
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
 
 
 def main() -> None:
@@ -275,7 +481,8 @@ def main() -> None:
     ap.add_argument("--steps", type=int, default=2)
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--copies", type=int, default=4096, help="Canterbury-like sets per GPU")
-    ap.add_argument("--seeds", type=int, default=8, help="distinct seeds among the copies")
+    ap.add_argument("--seeds", type=int, default=64,
+                    help="distinct seeds among the copies (64 x 11 = 704 distinct buffers, each replicated copies / 64 times)")
     ap.add_argument("--level", type=int, default=6)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--verify", type=int, default=-1,
@@ -293,6 +500,12 @@ def main() -> None:
                     help="64 KiB buffers of the level 1/6/9 section (BASELINE config 3; 0: skip)")
     ap.add_argument("--with-inflate", action="store_true",
                     help="also time the inflate kernel on the produced streams (extra field)")
+    ap.add_argument("--corpus-dir", default=os.environ.get("ZSC_CORPUS_DIR", ""),
+                    help="directory holding the real Canterbury files: compress them with max_block_len 100 000 "
+                         "and put the totals next to the reference's published ones (extra field)")
+    ap.add_argument("--config5", type=float, default=0.0,
+                    help="BASELINE config 5 instead of the headline: this many GiB (the config says 16) of 64 KiB "
+                         "buffers, a fixed batch cut over the GPUs by a cost proxy, staged on GPU 0")
     ap.add_argument("--max-block-len", type=int, default=0,
                     help="also time the same buffers as streams of sections of this length "
                          "(zsc_compress with max_block_len < source_len; extra field)")
@@ -317,6 +530,9 @@ def main() -> None:
 
     if zsc_amd.lib.zsc_hip_init(local) != 0:
         raise SystemExit("zsc_amd: no usable gfx950 device (there is no CPU fallback)")
+    if args.config5 > 0:
+        run_config5(args, rank, world, local, dev)
+        return
 
     # ---- the workload: args.copies x world Canterbury-like sets; rank 0 scatters the ranges
     seeds = max(1, min(args.seeds, args.copies))
@@ -405,14 +621,20 @@ def main() -> None:
     oracle = Oracle()
     out_host = None
     nver = len(period_bufs) if args.verify < 0 else min(args.verify, len(period_bufs))
-    for i in range(nver):
-        k = i if nver == len(period_bufs) else (7 * i + 2) % len(period_bufs)
-        if out_host is None:
-            out_host = d_out[:plan.out_offsets[len(period_bufs) - 1] + plan.out_caps[len(period_bufs) - 1]].cpu()
-        got = bytes(out_host[plan.out_offsets[k]:plan.out_offsets[k] + lens[k]].numpy())
-        rc, want, _ = oracle.compress(period_bufs[k], args.level)
-        if rc != 0 or got != want:
-            raise SystemExit(f"rank {rank}: buffer {k} differs from the oracle")
+    if nver:
+        from concurrent.futures import ThreadPoolExecutor
+        out_host = d_out[:plan.out_offsets[len(period_bufs) - 1] + plan.out_caps[len(period_bufs) - 1]].cpu()
+        picks = [i if nver == len(period_bufs) else (7 * i + 2) % len(period_bufs) for i in range(nver)]
+
+        def check(k):  # (the checker's C code runs without the interpreter lock: one oracle per call is fine)
+            got = bytes(out_host[plan.out_offsets[k]:plan.out_offsets[k] + lens[k]].numpy())
+            rc, want, _ = Oracle().compress(period_bufs[k], args.level)
+            return k if (rc != 0 or got != want) else -1
+
+        with ThreadPoolExecutor(max_workers=max(1, min(16, os.cpu_count() or 1))) as ex:
+            wrong = [k for k in ex.map(check, picks) if k >= 0]
+        if wrong:
+            raise SystemExit(f"rank {rank}: buffer {wrong[0]} differs from the oracle")
     # the other copies: same length as, and on the device byte for byte equal to, the first copy
     nper = len(period_bufs)
     replicas_ok = all(lens[i] == lens[i % nper] for i in range(len(lens)))
@@ -575,8 +797,10 @@ def main() -> None:
                 info["cpu_baseline"] = cpu_inflate_baseline(members, outs)
             line["inflate"] = info
             torch.cuda.empty_cache()
+        if args.corpus_dir:
+            line["corpus"] = bench_corpus_dir(args.corpus_dir)
         if args.levels_64k > 0:
-            line["levels_64k"] = bench_levels_64k(dev, stream, args.levels_64k, fence)
+            line["levels_64k"] = bench_levels_64k(dev, stream, args.levels_64k, fence, not args.no_cpu_baseline)
     if rank == 0:
         print(json.dumps(line), flush=True)
     if world > 1:

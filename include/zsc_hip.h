@@ -157,6 +157,15 @@ ZlibReturn zsc_hip_inflate_plan_create(zsc_hip_inflate_plan **plan, U32 count,
                                        const U32 *source_lens, const uint64_t *src_offsets,
                                        const U32 *dest_caps, const uint64_t *dst_offsets,
                                        I32 window_bits);
+/* The same with the order in which the streams are handed to the wavefronts given by the caller:
+ * decode_order is a permutation of 0 .. count-1 (Z_STREAM_ERROR if it is not), NULL = the library's
+ * own order (longest output first).  Four streams share a wavefront, so a caller that knows which
+ * streams resemble each other can keep them apart or together; bench.py uses it to keep the replicas
+ * of one member of its replicated batch from sharing wavefronts. */
+ZlibReturn zsc_hip_inflate_plan_create_ordered(zsc_hip_inflate_plan **plan, U32 count,
+                                               const U32 *source_lens, const uint64_t *src_offsets,
+                                               const U32 *dest_caps, const uint64_t *dst_offsets,
+                                               I32 window_bits, const U32 *decode_order);
 ZlibReturn zsc_hip_inflate_plan_run(zsc_hip_inflate_plan *plan, const void *d_src, void *d_dst,
                                     void *hip_stream);
 ZlibReturn zsc_hip_inflate_plan_results(zsc_hip_inflate_plan *plan, U32 *dest_lens,

@@ -42,3 +42,16 @@ def gpu_available() -> bool:
         return torch.cuda.is_available()
     except Exception:
         return False
+
+
+@pytest.fixture(autouse=True)
+def _flush_c_stdio():
+    """The compiled reference reports through printf (its own example configuration header,
+    /root/reference/test/zsc_test_private.h:73-81): flush C stdio while pytest still captures the test's
+    output, so that those lines stay with their test instead of pouring out when the process exits."""
+    yield
+    try:
+        import ctypes
+        ctypes.CDLL(None).fflush(None)
+    except Exception:
+        pass

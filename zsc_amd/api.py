@@ -73,6 +73,8 @@ def _load() -> C.CDLL:
                                            C.POINTER(C.c_void_p), u32p, i32p, C.c_int32]
     L.zsc_hip_inflate_plan_create.argtypes = [C.POINTER(C.c_void_p), C.c_uint32, u32p, u64p, u32p,
                                               u64p, C.c_int32]
+    L.zsc_hip_inflate_plan_create_ordered.argtypes = [C.POINTER(C.c_void_p), C.c_uint32, u32p, u64p, u32p,
+                                                      u64p, C.c_int32, u32p]
     L.zsc_hip_inflate_plan_run.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
     L.zsc_hip_inflate_plan_results.argtypes = [C.c_void_p, u32p, u32p, i32p, C.POINTER(C.c_float)]
     L.zsc_hip_inflate_plan_destroy.argtypes = [C.c_void_p]
@@ -329,7 +331,7 @@ class InflatePlan:
     """Device-resident inflate batch (see include/zsc_hip.h)."""
 
     def __init__(self, source_lens: Sequence[int], dest_caps: Sequence[int],
-                 window_bits: int = DEF_WBITS):
+                 window_bits: int = DEF_WBITS, decode_order: Sequence[int] | None = None):
         self.count = n = len(source_lens)
         so, do, sb, db = [], [], 0, 0
         for sl, dc in zip(source_lens, dest_caps):
@@ -340,9 +342,10 @@ class InflatePlan:
         self.src_offsets, self.dst_offsets = so, do
         self.src_bytes, self.dst_bytes = sb + 64, db + 64
         self._h = C.c_void_p()
-        rc = lib.zsc_hip_inflate_plan_create(C.byref(self._h), n, (C.c_uint32 * n)(*source_lens),
-                                             (C.c_uint64 * n)(*so), (C.c_uint32 * n)(*dest_caps),
-                                             (C.c_uint64 * n)(*do), window_bits)
+        order = None if decode_order is None else (C.c_uint32 * n)(*decode_order)
+        rc = lib.zsc_hip_inflate_plan_create_ordered(C.byref(self._h), n, (C.c_uint32 * n)(*source_lens),
+                                                     (C.c_uint64 * n)(*so), (C.c_uint32 * n)(*dest_caps),
+                                                     (C.c_uint64 * n)(*do), window_bits, order)
         if rc != Z_OK:
             raise RuntimeError(f"zsc_hip_inflate_plan_create failed: {rc}")
 

@@ -2216,11 +2216,12 @@ struct zsc_hip_inflate_plan {
     bool timed = false;
 };
 
-extern "C" ZlibReturn zsc_hip_inflate_plan_create(zsc_hip_inflate_plan **plan_out, U32 count,
+extern "C" ZlibReturn zsc_hip_inflate_plan_create_ordered(zsc_hip_inflate_plan **plan_out, U32 count,
                                                   const U32 *source_lens,
                                                   const uint64_t *src_offsets,
                                                   const U32 *dest_caps,
-                                                  const uint64_t *dst_offsets, I32 window_bits)
+                                                  const uint64_t *dst_offsets, I32 window_bits,
+                                                       const U32 *decode_order)
 {
     DeviceScope scope;
     ZSC_ASSERT(plan_out != Z_NULL);
@@ -2247,19 +2248,18 @@ extern "C" ZlibReturn zsc_hip_inflate_plan_create(zsc_hip_inflate_plan **plan_ou
     }
     std::stable_sort(order.begin(), order.end(),
                      [&](uint32_t a, uint32_t b) { return items[a].dst_cap > items[b].dst_cap; });
-    if (const char *e = getenv("ZSC_HIP_INFLATE_SPREAD")) {
-        /* measurement aid: a benchmark batch of D distinct streams replicated R times puts the R
-         * copies of a stream next to each other in the length order, so the streams that share a
-         * wavefront are identical and never diverge.  With D given, neighbours in the order are
-         * DIFFERENT streams of nearly the same length -- what a batch of all-different streams
-         * looks like. */
-        const uint32_t d = (uint32_t)atoi(e);
-        if (d > 1 && count % d == 0) {
-            const uint32_t r = count / d;
-            std::vector<uint32_t> spread(count);
-            for (uint32_t s2 = 0; s2 < count; s2++)
-                spread[s2] = order[(s2 % d) * r + s2 / d];
-            order.swap(spread);
+    if (decode_order) {
+        /* the caller's order: a permutation of the streams (checked), e.g. to keep the replicas of one
+         * stream of a benchmark batch from sharing wavefronts (bench.py) */
+        std::vector<uint8_t> seen(count, 0);
+        for (uint32_t k = 0; k < count; k++) {
+            if (decode_order[k] >= count || seen[decode_order[k]]) {
+                ZSC_WARN1("zsc_hip: decode_order is not a permutation (entry %u).", k);
+                delete pl;
+                return Z_STREAM_ERROR;
+            }
+            seen[decode_order[k]] = 1;
+            order[k] = decode_order[k];
         }
     }
     bool ok = pl->d_items.ensure(sizeof(ZdInfItem) * std::max(1u, count)) &&
@@ -2285,6 +2285,16 @@ extern "C" ZlibReturn zsc_hip_inflate_plan_create(zsc_hip_inflate_plan **plan_ou
     (void)hipEventCreate(&pl->ev1);
     *plan_out = pl;
     return Z_OK;
+}
+
+extern "C" ZlibReturn zsc_hip_inflate_plan_create(zsc_hip_inflate_plan **plan_out, U32 count,
+                                                  const U32 *source_lens,
+                                                  const uint64_t *src_offsets,
+                                                  const U32 *dest_caps,
+                                                  const uint64_t *dst_offsets, I32 window_bits)
+{
+    return zsc_hip_inflate_plan_create_ordered(plan_out, count, source_lens, src_offsets, dest_caps, dst_offsets,
+                                               window_bits, Z_NULL);
 }
 
 extern "C" ZlibReturn zsc_hip_inflate_plan_run(zsc_hip_inflate_plan *pl, const void *d_src,
