@@ -258,6 +258,8 @@ extern "C" int emu_table_check(const uint8_t *src, uint32_t n, int level, int st
     return bad;
 }
 
+static int g_fast_global = 1;
+extern "C" void emu_set_fast_global(int on) { g_fast_global = on; }
 int g_seg_mode = 0; /* 0: runtime's choice, 1: force wave-per-buffer, 2: segmented, segments handed out last first,
                        3: segmented, first first (a parser never finds its successors' traces) */
 extern "C" void emu_set_seg_mode(int m) { g_seg_mode = m; }
@@ -350,10 +352,17 @@ static void run_parse(const LzJob &job)
             EMU_LAZY(LzLds4k);
 #undef EMU_LAZY
     } else {
-        LzLdsFast *lds = (LzLdsFast *)malloc(sizeof(LzLdsFast));
-        memset(lds, 0xA5, sizeof(LzLdsFast));
-        lz_parse_greedy(job, lds);
-        free(lds);
+        if (g_fast_global) { /* the product's choice: the window read from the input, no LDS ring */
+            LzLdsFastG *lds = (LzLdsFastG *)malloc(sizeof(LzLdsFastG));
+            memset(lds, 0xA5, sizeof(LzLdsFastG));
+            lz_parse_greedy<LzLdsFastG>(job, lds);
+            free(lds);
+        } else {
+            LzLdsFast *lds = (LzLdsFast *)malloc(sizeof(LzLdsFast));
+            memset(lds, 0xA5, sizeof(LzLdsFast));
+            lz_parse_greedy<LzLdsFast>(job, lds);
+            free(lds);
+        }
     }
 }
 

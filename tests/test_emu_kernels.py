@@ -201,6 +201,28 @@ def test_segmented_parser_search_modes(emu, oracle):
         emu.emu_set_stair_min(0)
 
 
+def test_greedy_parser_with_and_without_an_lds_window(emu, oracle):
+    """Levels 1-3 (deflate_fast): the parser that reads the window from the input itself (the product's
+    choice) and the one with an LDS ring give the oracle's streams, through window slides and at the
+    edges of the input."""
+    if emu.inflate_only or emu.group16:
+        pytest.skip("the wave-per-buffer parsers are whole-wave code: 64 lanes only")
+    try:
+        for glob in (1, 0):
+            emu.emu_set_fast_global(glob)
+            for n in (0, 1, 3, 4, 262, 4097, 40959, 40960, 40961, 65275, 65536, 70001, 131072):
+                for kind in ("text", "runs", "random", "zero", "bitmap"):
+                    data = corpus.make_buffer(kind, n, n + 19)
+                    for level in (1, 2, 3):
+                        if n > 70001 and level != 1:
+                            continue
+                        rc, got = emu_compress(emu, data, level, 1)
+                        orc, want, _ = oracle.compress(data, level)
+                        assert rc == orc == 0 and got == want, (glob, n, kind, level)
+    finally:
+        emu.emu_set_fast_global(1)
+
+
 def emu_uncompress(L, data, cap, wb):
     dst = C.create_string_buffer(max(cap, 1))
     ol, used = C.c_uint32(), C.c_uint32()

@@ -39,6 +39,7 @@ struct LzLdsT {
     static constexpr uint32_t RING = RING_BYTES, CHUNK = CHUNK_BYTES;
     static constexpr bool HAS_INS = WITH_HOLES; /* lz_load_chunk clears ins[] for what enters the ring */
     static constexpr bool HOLES = WITH_HOLES;
+    static constexpr bool GLOBAL_WIN = false; /* the window is the LDS ring */
     static constexpr uint32_t PR = LZ_PR;
     uint8_t ring[RING + 512]; /* sliding window; first 16 bytes mirrored after the end, rest slack for masked over-reads */
     uint32_t stage[WAVE];     /* symbols waiting for a coalesced store */
@@ -67,6 +68,7 @@ struct LzLdsFast {
     static constexpr uint32_t RING = 34816u, CHUNK = 2048u;
     static constexpr bool HAS_INS = true;
     static constexpr bool HOLES = false;
+    static constexpr bool GLOBAL_WIN = false;
     static constexpr uint32_t PR = LZ_PR_FAST;
     uint8_t ring[RING + 512];
     uint32_t stage[WAVE];
@@ -74,6 +76,24 @@ struct LzLdsFast {
     /* rank[] / hib[] of the next positions, 64 per coalesced load (as the lazy parser's prank / phib,
      * but 128 entries: with 512 the fifth KiB would cost the fourth wave of a CU) -- reading them from
      * global memory position by position was a dependent round trip per searched position */
+    uint16_t prank[LZ_PR_FAST];
+    uint16_t phib[LZ_PR_FAST];
+};
+
+/* The greedy parser without a window in LDS.  At levels 1-3 a search looks at a handful of
+ * candidates (max_chain 4 .. 32, nice 8 .. 32): their bytes come through the caches from the input
+ * itself, and what is left in LDS is the "was inserted" map (one bit per position of a 40 KiB span)
+ * and the staging areas -- 6 KiB instead of 40, so a CU holds 24 parsers instead of 4 (the parse
+ * is a chain of latencies per position: what it needs is more of them in flight). */
+struct LzLdsFastG {
+    static constexpr uint32_t RING = 40960u, CHUNK = 2048u; /* (the span of the map: the window and what lies ahead of it; nothing is copied) */
+    static constexpr bool HAS_INS = true;
+    static constexpr bool HOLES = false;
+    static constexpr bool GLOBAL_WIN = true;
+    static constexpr uint32_t PR = LZ_PR_FAST;
+    uint8_t ring[16]; /* (not used) */
+    uint32_t stage[WAVE];
+    uint32_t ins[RING / 32];
     uint16_t prank[LZ_PR_FAST];
     uint16_t phib[LZ_PR_FAST];
 };
@@ -121,13 +141,45 @@ DEV uint32_t lz_ridx(const LzState &st, uint32_t pos)
     return r >= L::RING ? r - L::RING : r;
 }
 
+/* four / one byte(s) of the window at an absolute position: from the LDS ring, or -- a parser
+ * without one -- from the input itself, bytes behind it reading as zero like the ring's */
+template <class L>
+DEV uint32_t lz_w32(const LzJob &job, const L *lds, const LzState &st, uint32_t pos)
+{
+    if constexpr (L::GLOBAL_WIN) {
+        (void)lds;
+        (void)st;
+        if ((uint64_t)pos + 4u <= job.ntot)
+            return ld_u32(job.in + pos);
+        uint32_t v = 0;
+        for (uint32_t k = 0; k < 4u; k++)
+            v |= (pos + k < job.ntot ? (uint32_t)job.in[pos + k] : 0u) << (8u * k);
+        return v;
+    } else {
+        (void)job;
+        return lds_u32(lds->ring, lz_ridx<L>(st, pos));
+    }
+}
+template <class L>
+DEV uint32_t lz_w8(const LzJob &job, const L *lds, const LzState &st, uint32_t pos)
+{
+    if constexpr (L::GLOBAL_WIN) {
+        (void)lds;
+        (void)st;
+        return pos < job.ntot ? (uint32_t)job.in[pos] : 0u;
+    } else {
+        (void)job;
+        return lds->ring[lz_ridx<L>(st, pos)];
+    }
+}
+
 /* bring [hi, hi+CHUNK) into the ring (chunk-aligned, 16 bytes per lane per step) */
 template <class L>
 DEV void lz_load_chunk(const LzJob &job, L *lds, LzState &st)
 {
     const uint32_t a0 = st.hi; /* multiple of CHUNK */
     const uint32_t r0 = lz_ridx<L>(st, a0);
-    for (uint32_t k = 0; k < L::CHUNK; k += WAVE * 16) {
+    for (uint32_t k = 0; k < L::CHUNK && !L::GLOBAL_WIN; k += WAVE * 16) {
         FOR_LANES
         {
             uint32_t off = k + (uint32_t)LANE * 16u;
@@ -153,7 +205,7 @@ DEV void lz_load_chunk(const LzJob &job, L *lds, LzState &st)
         }
     }
     WAVE_SYNC();
-    if (r0 == 0) {
+    if (r0 == 0 && !L::GLOBAL_WIN) {
         FOR_LANES
         {
             if (LANE < 16)
@@ -287,14 +339,14 @@ DEV void lz_refill(const LzJob &job, LzState &st, uint32_t p)
 
 /* cooperative longest-common-prefix of the strings at q and p, at most cap (<=258) bytes */
 template <class L>
-DEV uint32_t lz_lcp(const L *lds, const LzState &st, uint32_t q, uint32_t p, uint32_t cap)
+DEV uint32_t lz_lcp(const LzJob &job, const L *lds, const LzState &st, uint32_t q, uint32_t p, uint32_t cap)
 {
     LANEVAR(uint32_t, diff);
     LANEVAR(int, differs);
     FOR_LANES
     {
-        uint32_t a = lds_u32(lds->ring, lz_ridx<L>(st, q + 4u * (uint32_t)LANE));
-        uint32_t b = lds_u32(lds->ring, lz_ridx<L>(st, p + 4u * (uint32_t)LANE));
+        uint32_t a = lz_w32<L>(job, lds, st, (q + 4u * (uint32_t)LANE));
+        uint32_t b = lz_w32<L>(job, lds, st, (p + 4u * (uint32_t)LANE));
         LV(diff) = a ^ b;
         LV(differs) = LV(diff) != 0;
     }
@@ -306,9 +358,9 @@ DEV uint32_t lz_lcp(const L *lds, const LzState &st, uint32_t q, uint32_t p, uin
         len = 4u * (uint32_t)f + ((uint32_t)CTZ32(x) >> 3);
     } else {
         len = 256;
-        if (cap > 256 && UNI(lds->ring[lz_ridx<L>(st, q + 256)]) == UNI(lds->ring[lz_ridx<L>(st, p + 256)])) {
+        if (cap > 256 && UNI(lz_w8<L>(job, lds, st, q + 256)) == UNI(lz_w8<L>(job, lds, st, p + 256))) {
             len = 257;
-            if (cap > 257 && UNI(lds->ring[lz_ridx<L>(st, q + 257)]) == UNI(lds->ring[lz_ridx<L>(st, p + 257)]))
+            if (cap > 257 && UNI(lz_w8<L>(job, lds, st, q + 257)) == UNI(lz_w8<L>(job, lds, st, p + 257)))
                 len = 258;
         }
     }
@@ -360,7 +412,7 @@ DEV void lz_ensure_ranks(const LzJob &job, L *lds, LzState &st, uint32_t p)
     do {                                                                                      \
         (blocked) = 0;                                                                        \
         const uint32_t _hs = (job.cfg.hbits + 2u) / 3u, _hm = (1u << job.cfg.hbits) - 1u;     \
-        const uint32_t _wp = UNI(lds_u32(lds->ring, lz_ridx<L>(st, (P))));                    \
+        const uint32_t _wp = UNI(lz_w32<L>(job, lds, st, ((P))));                    \
         const uint32_t _hp = (((_wp & 0xffu) << (2u * _hs)) ^ (((_wp >> 8) & 0xffu) << _hs) ^ \
                               ((_wp >> 16) & 0xffu)) & _hm;                                   \
         for (uint32_t _x0 = (Q) + 1u; _x0 < (P) && !(blocked); _x0 += WAVE) {                 \
@@ -370,7 +422,7 @@ DEV void lz_ensure_ranks(const LzJob &job, L *lds, LzState &st, uint32_t p)
                 const uint32_t _x = _x0 + (uint32_t)LANE;                                     \
                 int _s = 0;                                                                   \
                 if (_x < (P)) {                                                               \
-                    const uint32_t _w = lds_u32(lds->ring, lz_ridx<L>(st, _x));               \
+                    const uint32_t _w = lz_w32<L>(job, lds, st, (_x));               \
                     const uint32_t _h = (((_w & 0xffu) << (2u * _hs)) ^                       \
                                          (((_w >> 8) & 0xffu) << _hs) ^ ((_w >> 16) & 0xffu)) & _hm; \
                     _s = _h == _hp && MEMB(_x);                                               \
@@ -381,6 +433,10 @@ DEV void lz_ensure_ranks(const LzJob &job, L *lds, LzState &st, uint32_t p)
                 (blocked) = 1;                                                                \
         }                                                                                     \
     } while (0)
+
+/* four bytes of the string being searched for, as a wave-uniform value: from the window, unless the
+ * parser keeps them in registers (lz_parse_greedy redefines this) */
+#define LZ_SPEEK32(pos) UNI(lz_w32<L>(job, lds, st, (pos)))
 
 /* search context shared by the batch evaluator */
 typedef struct {
@@ -504,15 +560,15 @@ DEV void lz_mark_holes(L *lds, const LzState &st, uint32_t old_n, uint32_t p_nex
                 (verdict) = 2;                                                                \
                 break;                                                                        \
             }                                                                                 \
-            sc.sb = UNI((lds_u32(lds->ring, lz_ridx<L>(st, sc.p + sc.best - 1)) & 0xffffu));              \
+            sc.sb = LZ_SPEEK32(sc.p + sc.best - 1) & 0xffffu;                                     \
         }                                                                                     \
         const int _ends = ((_m_hash & ~_m_reach) | (_m_in & ~_m_alive)) != 0; /* chain leaves the window */         \
         FOR_LANES                                                                             \
         {                                                                                     \
             int _c = 0;                                                                       \
             if (LV(_alive)) {                                                                 \
-                _c = (lds_u32(lds->ring, lz_ridx<L>(st, LV(_q))) & 0xffffu) == sc.s01 &&                  \
-                     (lds_u32(lds->ring, lz_ridx<L>(st, LV(_q) + sc.best - 1)) & 0xffffu) == sc.sb;       \
+                _c = (lz_w32<L>(job, lds, st, (LV(_q))) & 0xffffu) == sc.s01 &&                  \
+                     (lz_w32<L>(job, lds, st, (LV(_q) + sc.best - 1)) & 0xffffu) == sc.sb;       \
             }                                                                                 \
             LV(_pass) = _c;                                                                   \
         }                                                                                     \
@@ -521,7 +577,7 @@ DEV void lz_mark_holes(L *lds, const LzState &st, uint32_t old_n, uint32_t p_nex
         while (_todo != 0) {                                                                  \
             const int _j = CTZ64(_todo);                                                      \
             const uint32_t _qj = READLANE(_q, _j);                                            \
-            const uint32_t _len = lz_lcp<L>(lds, st, _qj, sc.p, sc.cap);                      \
+            const uint32_t _len = lz_lcp<L>(job, lds, st, _qj, sc.p, sc.cap);                      \
             if (_len > sc.best) {                                                             \
                 sc.where = _qj;                                                               \
                 sc.best = _len;                                                               \
@@ -529,13 +585,13 @@ DEV void lz_mark_holes(L *lds, const LzState &st, uint32_t old_n, uint32_t p_nex
                     (verdict) = 2;                                                            \
                     break;                                                                    \
                 }                                                                             \
-                sc.sb = UNI((lds_u32(lds->ring, lz_ridx<L>(st, sc.p + sc.best - 1)) & 0xffffu));          \
+                sc.sb = LZ_SPEEK32(sc.p + sc.best - 1) & 0xffffu;                                 \
                 FOR_LANES                                                                     \
                 {                                                                             \
                     int _c = 0;                                                               \
                     if (LV(_alive) && LANE > _j) {                                            \
-                        _c = (lds_u32(lds->ring, lz_ridx<L>(st, LV(_q))) & 0xffffu) == sc.s01 &&          \
-                             (lds_u32(lds->ring, lz_ridx<L>(st, LV(_q) + sc.best - 1)) & 0xffffu) == sc.sb; \
+                        _c = (lz_w32<L>(job, lds, st, (LV(_q))) & 0xffffu) == sc.s01 &&          \
+                             (lz_w32<L>(job, lds, st, (LV(_q) + sc.best - 1)) & 0xffffu) == sc.sb; \
                     }                                                                         \
                     LV(_pass) = _c;                                                           \
                 }                                                                             \
@@ -630,7 +686,7 @@ DEV void lz_parse_lazy(const LzJob &job, L *lds)
                     break;
                 /* a joint: src/deflate.c:2108-2113, then the next call carries on from here */
                 if (pending) {
-                    (void)lz_put<L>(job, lds, st, UNI(lds->ring[lz_ridx<L>(st, p - 1)]));
+                    (void)lz_put<L>(job, lds, st, UNI(lz_w8<L>(job, lds, st, p - 1)));
                     pending = 0;
                 }
                 if (!lz_joint_at_end(job, st, p))
@@ -670,7 +726,7 @@ DEV void lz_parse_lazy(const LzJob &job, L *lds)
         if (searching) {
             LzSearch sc;
             sc.p = p;
-            const uint32_t w0 = UNI(lds_u32(lds->ring, lz_ridx<L>(st, p)));
+            const uint32_t w0 = UNI(lz_w32<L>(job, lds, st, (p)));
             sc.h = (((w0 & 0xff) << 10) ^ (((w0 >> 8) & 0xff) << 5) ^ ((w0 >> 16) & 0xff)) & ZD_HASH_MASK;
             sc.s01 = w0 & 0xffff;
             sc.sb = 0;
@@ -717,7 +773,7 @@ DEV void lz_parse_lazy(const LzJob &job, L *lds)
                     lz_mark_holes<L>(lds, st, old_n, p);
             }
         } else if (pending) {
-            const uint32_t c = UNI(lds->ring[lz_ridx<L>(st, p - 1)]);
+            const uint32_t c = UNI(lz_w8<L>(job, lds, st, p - 1));
             uint32_t old_n = 0xffffffffu;
             if (lz_put<L>(job, lds, st, c))
                 old_n = lz_cut(job, st, p, 0, ZD_CUT_FULL);
@@ -730,7 +786,7 @@ DEV void lz_parse_lazy(const LzJob &job, L *lds)
         }
     }
     if (pending)
-        (void)lz_put<L>(job, lds, st, UNI(lds->ring[lz_ridx<L>(st, p - 1)]));
+        (void)lz_put<L>(job, lds, st, UNI(lz_w8<L>(job, lds, st, p - 1)));
     lz_cut_end(job, st, p);
     if (st.nstaged)
         lz_flush_stage<L>(job, lds, st);
@@ -753,9 +809,26 @@ DEV void lz_mark_inserted(L *lds, const LzState &st, uint32_t x)
 /* deflate_fast, reference src/deflate.c:1886-1982 (levels 1-3), flush == Z_FINISH.
  * Same candidate machinery as the lazy parser; a candidate belongs to the chain only
  * if the parse inserted it (short matches index their interior, long ones do not). */
-DEV void lz_parse_greedy(const LzJob &job, LzLdsFast *lds)
+/* The bytes ahead of the parse in registers: lane l holds the dword at wc_at + 4 l, so that what a
+ * loop top reads of its own string (the first four bytes, the two at best_len - 1, the literal) costs
+ * two v_readlane and a shift instead of a trip to memory -- for the parser without an LDS window
+ * that trip is a global load in the middle of every position's chain of dependent steps. */
+#undef LZ_SPEEK32
+#define LZ_SPEEK32(pos) lz_cached32<L>(job, lds, st, wc, wc_at, (pos))
+template <class L, class V>
+DEV uint32_t lz_cached32(const LzJob &job, const L *lds, const LzState &st, const V &wc, uint32_t wc_at, uint32_t pos)
 {
-    typedef LzLdsFast L;
+    const uint32_t d = pos - wc_at;
+    if (d <= 4u * (WAVE - 2u)) {
+        const uint32_t lo = READLANE(wc, d >> 2), hi = READLANE(wc, (d >> 2) + 1u);
+        return (uint32_t)((((uint64_t)hi << 32) | lo) >> (8u * (d & 3u)));
+    }
+    return UNI(lz_w32<L>(job, lds, st, pos));
+}
+
+template <class L>
+DEV void lz_parse_greedy(const LzJob &job, L *lds)
+{
     LzState st;
     st.lo = st.hi = st.wrap_base = 0;
     st.base = 0;
@@ -779,6 +852,9 @@ DEV void lz_parse_greedy(const LzJob &job, LzLdsFast *lds)
     LANEVAR(uint32_t, nA);
     LANEVAR(uint32_t, nB);
     uint32_t n_at = 0xffffffffu;
+    LANEVAR(uint32_t, wc);
+    FOR_LANES { LV(wc) = 0; }
+    uint32_t wc_at = 0x80000000u; /* (no position of a buffer is within reach of it: buffers are shorter than 2^29) */
     for (;;) {
         st.it = p;
         uint32_t look = st.data_end - p;
@@ -806,12 +882,16 @@ DEV void lz_parse_greedy(const LzJob &job, LzLdsFast *lds)
             }
         }
         lz_ensure<L>(job, lds, st, p);
+        if (p - wc_at > 4u * (WAVE - 2u) - 8u) { /* (p and the few bytes behind it are always in reach) */
+            wc_at = p & ~3u;
+            FOR_LANES { LV(wc) = lz_w32<L>(job, lds, st, wc_at + 4u * (uint32_t)LANE); }
+        }
 
         if (look >= 3) {
             lz_mark_inserted<L>(lds, st, p);
             LzSearch sc;
             sc.p = p;
-            const uint32_t w0 = UNI(lds_u32(lds->ring, lz_ridx<L>(st, p)));
+            const uint32_t w0 = LZ_SPEEK32(p);
             sc.h = (((w0 & 0xff) << 10) ^ (((w0 >> 8) & 0xff) << 5) ^ ((w0 >> 16) & 0xff)) & ZD_HASH_MASK;
             sc.s01 = w0 & 0xffff;
             sc.sb = 0;
@@ -881,7 +961,7 @@ DEV void lz_parse_greedy(const LzJob &job, LzLdsFast *lds)
                 len = 0;
             }
         } else {
-            full = lz_put<L>(job, lds, st, UNI(lds->ring[lz_ridx<L>(st, p)]));
+            full = lz_put<L>(job, lds, st, LZ_SPEEK32(p) & 0xffu);
             p++;
         }
         if (full)
@@ -896,5 +976,8 @@ DEV void lz_parse_greedy(const LzJob &job, LzLdsFast *lds)
         job.out->nblocks = st.nblocks;
     }
 }
+
+#undef LZ_SPEEK32
+#define LZ_SPEEK32(pos) UNI(lz_w32<L>(job, lds, st, (pos)))
 
 #endif

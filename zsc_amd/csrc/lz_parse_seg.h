@@ -103,6 +103,7 @@ struct SgLds {
     static constexpr uint32_t CHUNK = 2048u;
     static constexpr uint32_t RING = (ZD_TILE + SG_SPAN + SG_OV + 2u * ZD_MIN_LOOKAHEAD + 2u * CHUNK - 1u) / CHUNK * CHUNK;
     static constexpr bool HAS_INS = false;
+    static constexpr bool GLOBAL_WIN = false;
     uint8_t ring[RING + 512];
     uint32_t trace[SG_NS][SG_TRACE / 32];
     uint32_t tkind[SG_NS][SG_TRACE / 32]; /* for the positions in trace: 1 = a literal was owed there */
@@ -760,7 +761,22 @@ DEV void sg_parse_segment(const LzJob &job, SgLds *lds, const SgScratch &scr, ui
             }
             const uint32_t rh = GREADLANE(mrk, p - mt_at), cn = GREADLANE(mcn, p - mt_at);
             const uint32_t nA = cn & 0xffffu, total = nA + (cn >> 16);
-            if (total != 0) {
+            /* A match pending: anything longer shares prev_len + 1 bytes with p, so every trigram in
+             * them has been seen before -- if one of them (of those whose chain lengths are in the
+             * register cache) has an EMPTY chain, there is nothing longer and no need to look. */
+            int none_longer = 0;
+            if (total != 0 && prev_len >= 3u) {
+                LANEVAR(int, empty);
+                const uint32_t l0 = p - mt_at;
+                FOR_GLANES
+                {
+                    const uint32_t l = (uint32_t)GLANE;
+                    LV(empty) = l > l0 && l <= l0 + (prev_len - 2u) && LV(mcn) == 0u && (uint64_t)mt_at + l + 3u <= job.n;
+                }
+                none_longer = GBALLOT(empty) != 0;
+                SG_COUNT(9, (unsigned)none_longer);
+            }
+            if (total != 0 && !none_longer) {
                 SG_COUNT(5, 1);
                 const int32_t hiA = (int32_t)(rh & 0xffffu) - 1, hiB = (int32_t)(rh >> 16);
                 const uint32_t tileA = p & ~ZD_TILE_MASK;

@@ -441,6 +441,7 @@ __global__ __launch_bounds__(64) void k_parse_simple(const uint8_t *__restrict__
 }
 
 /* kernel 2 for levels 1-3 (greedy parse) */
+template <class L> /* LzLdsFastG: the window read from the input; LzLdsFast: an LDS ring (four waves per CU) */
 __global__ __launch_bounds__(64) void k_parse_fast(const uint8_t *__restrict__ in,
                                                    const ZdBuf *__restrict__ bufs,
                                                    const uint32_t *__restrict__ order,
@@ -453,7 +454,7 @@ __global__ __launch_bounds__(64) void k_parse_fast(const uint8_t *__restrict__ i
                                                    const ZdSched *__restrict__ sched,
                                                    const ZdLevel cfg, uint32_t nbuf)
 {
-    __shared__ LzLdsFast lds;
+    __shared__ L lds;
     if (blockIdx.x >= nbuf)
         return;
     const uint32_t b = order[blockIdx.x];
@@ -477,7 +478,7 @@ __global__ __launch_bounds__(64) void k_parse_fast(const uint8_t *__restrict__ i
     job.sched = sched + buf.sched_off;
     job.nsched = buf.sched_n;
     job.n0 = buf.n0;
-    lz_parse_greedy(job, &lds);
+    lz_parse_greedy<L>(job, &lds);
 }
 
 /* kernel 3: one wavefront per (possible) block */
@@ -1293,7 +1294,8 @@ extern "C" ZlibReturn zsc_hip_deflate_plan_run(zsc_hip_deflate_plan *pl, const v
             }
 #undef ZSC_LAUNCH_PARSE
         } else
-            hipLaunchKernelGGL(k_parse_fast, dim3(sb.count), dim3(64), 0, st, in, bufs,
+            hipLaunchKernelGGL(getenv("ZSC_HIP_FAST_RING") ? k_parse_fast<LzLdsFast> : k_parse_fast<LzLdsFastG>,
+                               dim3(sb.count), dim3(64), 0, st, in, bufs,
                                (const uint32_t *)sb.d_order.p, (const uint32_t *)sorted,
                                (const uint16_t *)rank, (const uint16_t *)hib, tmp_syms, recs,
                                pout, (const ZdSched *)pl->d_sched.p, cfg, sb.count);
