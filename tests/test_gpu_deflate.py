@@ -416,3 +416,34 @@ def test_match_table_and_search_modes_on_the_device(oracle):
             os.environ.pop(k, None)
             if v is not None:
                 os.environ[k] = v
+
+
+@pytest.mark.gpu
+def test_sections_many_rounds_memory_and_work_budget(oracle):
+    """The corner where nearly every section end lets the next section in (incompressible data, mem_level 1
+    -- blocks of 127 symbols -- and sections of a few hundred bytes): the run grows round by round.  The
+    stream still equals the oracle's, the rounds whose bytes are no longer in use are given back (the
+    library's log line reports the peak held), and a call that would need more parsing than its work
+    budget is refused with Z_STREAM_ERROR instead of running on."""
+    import subprocess, sys, textwrap
+    data_args = ("random", 60000, 11)
+    code = textwrap.dedent(f"""
+        import sys
+        sys.path.insert(0, {repr(os.path.dirname(HERE))})
+        import zsc_amd
+        from zsc_amd import corpus
+        from oracle.oracle_py import Oracle
+        data = corpus.make_buffer{data_args}
+        rc, outs, stats = zsc_amd.compress_sections_batch([data], [176], 6, 15, 1, 0)
+        want = Oracle().compress(data, 6, mem_level=1, max_block_len=176, dest_cap=len(outs[0]) + 64 if outs else 1 << 20,
+                                 work_len=1 << 20)
+        print("RESULT", rc, stats, (outs[0] == want[1]) if rc == 0 else None)
+    """)
+    env = dict(os.environ, ZSC_HIP_SECTIONS_LOG="1")
+    r = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=600)
+    assert "RESULT 0 [0] True" in r.stdout, (r.stdout[-500:], r.stderr[-1500:])
+    peaks = [int(l.split("peak held")[1].split()[0]) for l in r.stderr.splitlines() if "peak held" in l]
+    assert peaks and max(peaks) < 64 * len(corpus.make_buffer(*data_args)) + (8 << 20), peaks   # O(stream), not O(rounds x stream)
+    env = dict(os.environ, ZSC_HIP_SECTIONS_BUDGET_MB="1")
+    r = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=600)
+    assert "RESULT -2" in r.stdout, (r.stdout[-500:], r.stderr[-1500:])

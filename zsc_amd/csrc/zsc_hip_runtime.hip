@@ -1709,6 +1709,42 @@ struct HipSecRunner {
     std::vector<Round *> rounds;
     uint32_t parses = 0;
     ZlibReturn error = Z_OK;
+    const std::vector<SecStream> *streams = nullptr; /* whose runs say which rounds' bytes are still in use */
+    uint64_t parsed_bytes = 0, budget_bytes = ~0ull;  /* work budget: input bytes parsed over all rounds */
+    uint64_t held_bytes = 0, held_peak = 0;           /* compressed bytes of the rounds kept */
+
+    /* Bytes of a round are in use while a run that was parsed in it is still part of its stream (not
+     * about to be parsed again: `jobs`, and not swallowed by the run before it) or a finished stream
+     * is made of them.  Everything else is given back before the next round allocates: without this
+     * a stream that needs many rounds (short sections, tiny blocks, incompressible data: every
+     * section end a joint) held rounds x run bytes, hundreds of GB for a few MiB of input. */
+    void release_dead_rounds(const std::vector<SecRun *> &jobs)
+    {
+        if (!streams)
+            return;
+        std::vector<uint8_t> live(rounds.size(), 0);
+        for (const SecStream &st : *streams) {
+            if (st.done) {
+                for (const SecPiece &pc : st.pieces)
+                    if ((pc.kind == SEC_PIECE_RUN || pc.kind == SEC_PIECE_TAIL) && pc.round < live.size())
+                        live[pc.round] = 1;
+                continue;
+            }
+            for (const auto &kv : st.runs) {
+                const SecRun &r = kv.second;
+                if (r.blocks.empty() || std::find(jobs.begin(), jobs.end(), &r) != jobs.end())
+                    continue; /* never parsed yet, or about to be parsed again */
+                if (r.round < live.size())
+                    live[r.round] = 1;
+            }
+        }
+        for (size_t k = 0; k < rounds.size(); k++) {
+            if (rounds[k] && !live[k] && rounds[k]->d_out.p) {
+                held_bytes -= rounds[k]->d_out.bytes;
+                rounds[k]->d_out.release();
+            }
+        }
+    }
 
     ~HipSecRunner()
     {
@@ -1723,6 +1759,16 @@ struct HipSecRunner {
     {
         const auto t_begin = std::chrono::steady_clock::now();
         const U32 count = (U32)jobs.size();
+        release_dead_rounds(jobs);
+        for (const SecRun *r : jobs)
+            parsed_bytes += r->n;
+        if (parsed_bytes > budget_bytes) {
+            ZSC_WARN3("zsc_hip: compressing these streams of sections needs more than %llu MB of parsing for "
+                      "%u runs in round %u (sections so short, or blocks so small, that nearly every section end "
+                      "lets the next section in): refused.",
+                      (unsigned long long)(budget_bytes >> 20), count, round);
+            return error = Z_STREAM_ERROR;
+        }
         std::vector<U32> lens(count), caps(count), more(count), n0(count), soff(count), scnt(count), segok(count);
         std::vector<uint64_t> in_off(count), out_off(count);
         std::vector<ZdSched> sched;
@@ -1756,6 +1802,8 @@ struct HipSecRunner {
         rd->out_off = out_off;
         if (!rd->d_out.ensure(out_bytes))
             return error = Z_MEM_ERROR;
+        held_bytes += rd->d_out.bytes;
+        held_peak = std::max(held_peak, held_bytes);
 
         /* the scratch arrays of a plan are ~16 bytes per input byte: groups of jobs, one plan each,
          * all writing into the round's output */
@@ -1955,6 +2003,17 @@ static ZlibReturn sections_on_device(U32 count, const uint8_t *d_src, const uint
     runner.mem_level = mem_level;
     runner.wbits = wbits;
     runner.strategy = strategy;
+    runner.streams = &streams;
+    {
+        /* a run is parsed again from its start whenever a joint turns up behind it; 64 times the input
+         * (and 256 MB for small calls) is far beyond what any sensible call needs and bounds the rest */
+        uint64_t total = 0;
+        for (U32 i = 0; i < count; i++)
+            total += source_lens[i];
+        runner.budget_bytes = 64ull * total + (256ull << 20);
+        if (const char *e = getenv("ZSC_HIP_SECTIONS_BUDGET_MB")) /* (test hook) */
+            runner.budget_bytes = (uint64_t)atoll(e) << 20;
+    }
     const auto t_begin = std::chrono::steady_clock::now();
     if (rc == Z_OK) {
         const int e = sec_compress(streams, runner);
@@ -2028,9 +2087,11 @@ static ZlibReturn sections_on_device(U32 count, const uint8_t *d_src, const uint
     }
     if (getenv("ZSC_HIP_SECTIONS_LOG")) {
         const auto t_end = std::chrono::steady_clock::now();
-        fprintf(stderr, "zsc_hip sections: %u streams, rounds + simulation %.2f ms, putting together %.2f ms\n", count,
+        fprintf(stderr, "zsc_hip sections: %u streams, rounds + simulation %.2f ms, putting together %.2f ms; %u rounds, "
+                        "%llu input bytes parsed, compressed bytes of rounds peak held %llu\n", count,
                 std::chrono::duration<double, std::milli>(t_parsed - t_begin).count(),
-                std::chrono::duration<double, std::milli>(t_end - t_parsed).count());
+                std::chrono::duration<double, std::milli>(t_end - t_parsed).count(), (unsigned)runner.rounds.size(),
+                (unsigned long long)runner.parsed_bytes, (unsigned long long)runner.held_peak);
     }
     d_sbufs.release();
     d_sres.release();
