@@ -583,6 +583,7 @@ DEV void sg_phase_begin(const LzJob &job, SgLds *lds, int w)
         }                                                                                     \
         LV(hop) = h;                                                                          \
         LV(hby) = by;                                                                         \
+        LV(hr2) = (uint64_t)x + 4u <= job.n ? job.r2[x] : MT_INCOMPLETE;                      \
     }
 
 /* one token to the segment's token area (through a register, 64 at a time) */
@@ -646,7 +647,8 @@ DEV void sg_parse_segment(const LzJob &job, SgLds *lds, const SgScratch &scr, ui
     LANEVAR(uint32_t, sdx);
     LANEVAR(uint32_t, hop); /* hops of the positions from hop_at on, and the input bytes there */
     LANEVAR(uint32_t, hby);
-    FOR_GLANES { LV(mrk) = LV(mcn) = LV(pv) = LV(stg) = LV(sdx) = LV(hop) = LV(hby) = 0; }
+    LANEVAR(uint32_t, hr2); /* ... and their table entries themselves */
+    FOR_GLANES { LV(mrk) = LV(mcn) = LV(pv) = LV(stg) = LV(sdx) = LV(hop) = LV(hby) = LV(hr2) = 0; }
     uint32_t hop_at = p + 4096u; /* (out of range, as the other caches) */
     /* the two caches start out of range of p, so that their one range test fails */
     uint32_t mt_at = p + 4096u, pv_at = 0xffffffffu;
@@ -718,11 +720,11 @@ DEV void sg_parse_segment(const LzJob &job, SgLds *lds, const SgScratch &scr, ui
             }
         }
 
+        if (job.r2 != nullptr && p - hop_at >= GRP) {
+            hop_at = p;
+            SG_HOP_LOAD(p);
+        }
         if (job.r2 != nullptr && fresh) {
-            if (p - hop_at >= GRP) {
-                hop_at = p;
-                SG_HOP_LOAD(p);
-            }
             const uint32_t h = GREADLANE(hop, p - hop_at);
             if (h & SGH_VALID) {
                 const uint32_t by = GREADLANE(hby, p - hop_at);
@@ -748,7 +750,21 @@ DEV void sg_parse_segment(const LzJob &job, SgLds *lds, const SgScratch &scr, ui
         SG_PEEK32(p, s0123);
         const uint32_t prev_len = cur_len, prev_at = cur_at;
         cur_len = 2;
-        if (look >= 3 && prev_len < job.cfg.lazy) {
+        /* no hop, but the table may still know this one search: the entry itself when no match is
+         * pending, or -- where it says so -- what it implies for a longer prev_length */
+        int known = 0;
+        if (job.r2 != nullptr && look >= 3 && prev_len < job.cfg.lazy) {
+            const uint32_t a = GREADLANE(hr2, p - hop_at);
+            if (prev_len == 2u ? !(a & MT_INCOMPLETE) : (a & MT_RLOK) != 0u) {
+                known = 1;
+                SG_COUNT(10, 1);
+                if (MT_LEN(a) > prev_len) {
+                    cur_len = MT_LEN(a);
+                    cur_at = p - MT_DIST(a);
+                }
+            }
+        }
+        if (look >= 3 && prev_len < job.cfg.lazy && !known) {
             if (p - mt_at >= GRP - SG_PICK_AHEAD) { /* (and the positions a search may choose its chain from) */
                 mt_at = p;
                 FOR_GLANES

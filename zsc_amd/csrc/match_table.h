@@ -52,6 +52,10 @@
 #ifndef MT_STEPS
 #define MT_STEPS 3u /* records a search follows before it is left to the parser */
 #endif
+#ifndef MT_LCP
+#define MT_LCP 64u /* bytes a lane compares before the position is left to the parser (a run of equal bytes would
+                      cost every one of its positions 258 of them) */
+#endif
 #ifndef MT_CAP
 #define MT_CAP 16u /* entries of one chain a search looks at (MtJob.cap, a multiple of 4) */
 #endif
@@ -209,7 +213,9 @@ DEV uint32_t mt_search(const MtJob &job, const MtLds *lds, uint32_t p, uint32_t 
                 const uint32_t iq = cand ? q - wbase : ip;
                 const uint32_t two = (uint32_t)win[iq + b] << 8 | win[iq + b - 1u];
                 if (cand && two == sb) {
-                    const uint32_t len = mt_lcp(win, iq, ip, cap);
+                    const uint32_t len = mt_lcp(win, iq, ip, cap < MT_LCP ? cap : MT_LCP);
+                    if (len >= MT_LCP && len < cap)
+                        return MT_INCOMPLETE; /* a long one: the parser's wave compares 256 bytes a step */
                     if (len > b) {
                         found = 1;
                         fq = q;
