@@ -74,6 +74,9 @@
 #ifndef SG_PICK_AHEAD
 #define SG_PICK_AHEAD 16u /* positions from p on whose chain lengths a search must find in the register cache */
 #endif
+#ifndef SG_EMPTY_SKIP
+#define SG_EMPTY_SKIP 1 /* a pending match and an empty chain among the trigrams a longer one must contain: no search */
+#endif
 #ifndef SG_STAIR_MIN
 #define SG_STAIR_MIN 256u /* chains at least this long are searched as a staircase (LzJob.stair_min) */
 #endif
@@ -781,7 +784,7 @@ DEV void sg_parse_segment(const LzJob &job, SgLds *lds, const SgScratch &scr, ui
              * them has been seen before -- if one of them (of those whose chain lengths are in the
              * register cache) has an EMPTY chain, there is nothing longer and no need to look. */
             int none_longer = 0;
-            if (total != 0 && prev_len >= 3u) {
+            if (SG_EMPTY_SKIP && total != 0 && prev_len >= 3u) {
                 LANEVAR(int, empty);
                 const uint32_t l0 = p - mt_at;
                 FOR_GLANES

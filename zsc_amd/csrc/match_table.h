@@ -56,6 +56,9 @@
 #define MT_LCP 64u /* bytes a lane compares before the position is left to the parser (a run of equal bytes would
                       cost every one of its positions 258 of them) */
 #endif
+#ifndef MT_EARLY
+#define MT_EARLY 1 /* give a position up as soon as its shortest chain is longer than MT_CAP */
+#endif
 #ifndef MT_CAP
 #define MT_CAP 16u /* entries of one chain a search looks at (MtJob.cap, a multiple of 4) */
 #endif
@@ -193,6 +196,8 @@ DEV uint32_t mt_search(const MtJob &job, const MtLds *lds, uint32_t p, uint32_t 
         int found = 0, ended = 0;
         uint32_t fq = 0, flen = 0;
         open = 0;
+        if (b >= 3u && tj > job.cap && MT_EARLY)
+            return MT_INCOMPLETE; /* a chain longer than a lane walks: not worth starting on */
         const uint32_t lim = tj < job.cap ? tj : job.cap;
         uint32_t v = 0;
         /* four entries a trip (asked for together), each looked at with as few branches as it takes:
