@@ -1,19 +1,21 @@
 /*
- * match_table.h -- kernel 1c: longest_match for EVERY position, ahead of the parse.
+ * match_table.h -- kernel 1c (opt-in): longest_match for EVERY position, ahead of the parse.
  *
  * At levels 4-9 everything longest_match (reference src/deflate.c:1400-1518) reads is
  * independent of the parse -- the chains (every position is inserted, :2018,2069-2075), the
  * window base (a function of the position), lookahead and nice_match -- except prev_length,
  * the length it must beat.  And deflate_slow (:1989-2122) only ever calls it with two values
  * of prev_length at a position p: 2 (no match pending), or the length its own call at p-1
- * returned.  So a table with two entries per position answers every call the parse makes:
+ * returned.  So one table entry per position can answer every call the parse makes:
  *
- *   r2[p]  longest_match(p, prev_length = 2), after the TOO_FAR / Z_FILTERED rule (:2038-2047)
- *   rl[p]  longest_match(p, prev_length = length in r2[p-1]) where that is 3 .. max_lazy-1
+ *   r2[p]  longest_match(p, prev_length = 2), after the TOO_FAR / Z_FILTERED rule (:2038-2047);
+ *          flagged MT_RLOK when it also answers for ANY longer prev_length: the walk from a
+ *          longer prev_length ends at the same candidate, so the answer is "the same match if it
+ *          is longer than prev_length, none otherwise" (see below for when that is certain).
  *
- * (The call at p-1 may itself have been made with a pending match; if the chain budget ended
- * that walk elsewhere than the walk from 2, its result is not the key rl[p] was made for.  The
- * parser checks the key and searches itself in that case: lz_parse_seg.h.)
+ * The parser (lz_parse_seg.h) turns runs of known entries into HOPS -- everything deflate_slow does
+ * from one position with no match pending to the next such position follows from r2[x], r2[x+1],
+ * ... -- and uses single entries where a hop is not known.
  *
  * The search is NOT the reference's walk.  In zsc a candidate that fails the pre-check costs
  * nothing -- no chain budget, no change of best_len (:1462-1469) -- so as long as the budget
@@ -22,20 +24,27 @@
  * reached or the window ends.  A candidate longer than `best` shares best+1 bytes with p, so it
  * is on the chain of EVERY trigram p+j, j <= best-2, shifted by j: each step walks the shortest
  * of a few of those chains instead of p's own (the chain of " th" has 1 200 entries where the
- * one of "e q" has 12).  On the Canterbury-like text this looks at 5 candidates per input byte
- * where the reference's walk looks at 43, on the bitmap 3 instead of 260.
+ * one of "e q" has 12).  On the positions the parse really searches, the Canterbury-like text
+ * looks at 5 candidates per input byte this way where the reference's walk looks at 43, the
+ * bitmap at 3 instead of 260 (tools/rare_stats.c).
  *
  * The budget (:1430-1432,1508-1512) is charged by candidates that pass the pre-check.  While
  * best_len <= 4 those are exactly the improving ones (bytes best-1, best, 0, 1 and -- same hash,
  * same first two bytes -- byte 2 are then bytes 0..best); from best_len 5 on a candidate can
- * pass by coincidence.  An entry is only written when   records + (candidates of p's chain that
- * lie between the first record reached at a level >= 5 and the last record) < budget,   i.e.
- * when the budget cannot have ended the walk before the last record.  Everything else -- that
- * bound exceeded, or more than MT_CAP candidates looked at -- is left MT_INCOMPLETE and
- * searched by the parser on demand, with the walk it always had.
+ * pass by coincidence.  An entry is complete only when   steps + (entries of p's own chain that
+ * lie between the first step to a level >= 5 and the last step) < max_chain,   i.e. when the
+ * budget cannot have ended the walk before the last step; it is MT_RLOK only when   steps +
+ * (ALL entries of p's chain newer than the last step's candidate) < max_chain / 4,   the smallest
+ * budget and the earliest level >= 5 any longer prev_length can bring.  Everything else -- a chain
+ * longer than MT_CAP entries, more than MT_STEPS steps, a compare longer than MT_LCP bytes -- is
+ * left MT_INCOMPLETE and searched by the parser on demand.
  *
- * One workgroup per tile of 32 768 positions, the tile's window (the previous tile, the tile,
- * 512 bytes of lookahead) in LDS, a lane per position.
+ * One workgroup per tile of 32 768 positions, the tile's window (the previous tile, the tile, the
+ * lookahead) in LDS, a lane per position, straight-line code with fixed trip counts.  Measured
+ * (DESIGN.md section 5d): what the kernel costs is about what its hops save, so it is off by
+ * default (ZSC_HIP_TABLE); two earlier versions -- a per-lane loop without bounds, and lanes taking
+ * positions off a queue through a state machine of phases -- executed 5-7 times the instructions
+ * (profiles/r03_pmc_sq_table_queue_statemachine_text.txt).
  */
 #ifndef ZSC_MATCH_TABLE_H
 #define ZSC_MATCH_TABLE_H
