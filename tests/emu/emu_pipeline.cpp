@@ -290,7 +290,10 @@ static void run_parse_seg(const LzJob &job0, int order)
             /* waves run one after the other here, so the first one drains the queue */
             do {
                 for (int w = SG_W - 1; w >= 0; w--)
-                    sg_phase_parse(job, lds, scr, w);
+                    if (job.r2 != nullptr)
+                        sg_phase_parse<true>(job, lds, scr, w);
+                    else
+                        sg_phase_parse<false>(job, lds, scr, w);
                 for (int w = 0; w < SG_W; w++)
                     sg_phase_resolve(job, lds, scr, w);
             } while (lds->redo);

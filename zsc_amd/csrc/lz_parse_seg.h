@@ -75,7 +75,7 @@
 #define SG_PICK_AHEAD 16u /* positions from p on whose chain lengths a search must find in the register cache */
 #endif
 #ifndef SG_EMPTY_SKIP
-#define SG_EMPTY_SKIP 1 /* a pending match and an empty chain among the trigrams a longer one must contain: no search */
+#define SG_EMPTY_SKIP 0 /* (measured: text and incompressible data lose 3-5 % to the test, the table class gains 4 %) a pending match and an empty chain among the trigrams a longer one must contain: no search */
 #endif
 #ifndef SG_STAIR_MIN
 #define SG_STAIR_MIN 256u /* chains at least this long are searched as a staircase (LzJob.stair_min) */
@@ -609,6 +609,7 @@ DEV void sg_phase_begin(const LzJob &job, SgLds *lds, int w)
 /* parse from (p, cur_len, cur_at, pending) -- a state of the serial parse, or the fresh
  * state at the start of segment s -- until the parse can be handed to a later segment's
  * tokens, gives up, or leaves the super-step */
+template <bool TABLE> /* the buffer has a match table (job.r2): a build without it carries none of its code */
 DEV void sg_parse_segment(const LzJob &job, SgLds *lds, const SgScratch &scr, uint32_t s,
                           uint32_t p, uint32_t cur_len, uint32_t cur_at, int pending)
 {
@@ -723,11 +724,11 @@ DEV void sg_parse_segment(const LzJob &job, SgLds *lds, const SgScratch &scr, ui
             }
         }
 
-        if (job.r2 != nullptr && p - hop_at >= GRP) {
+        if (TABLE && p - hop_at >= GRP) {
             hop_at = p;
             SG_HOP_LOAD(p);
         }
-        if (job.r2 != nullptr && fresh) {
+        if (TABLE && fresh) {
             const uint32_t h = GREADLANE(hop, p - hop_at);
             if (h & SGH_VALID) {
                 const uint32_t by = GREADLANE(hby, p - hop_at);
@@ -756,7 +757,7 @@ DEV void sg_parse_segment(const LzJob &job, SgLds *lds, const SgScratch &scr, ui
         /* no hop, but the table may still know this one search: the entry itself when no match is
          * pending, or -- where it says so -- what it implies for a longer prev_length */
         int known = 0;
-        if (job.r2 != nullptr && look >= 3 && prev_len < job.cfg.lazy) {
+        if (TABLE && look >= 3 && prev_len < job.cfg.lazy) {
             const uint32_t a = GREADLANE(hr2, p - hop_at);
             if (prev_len == 2u ? !(a & MT_INCOMPLETE) : (a & MT_RLOK) != 0u) {
                 known = 1;
@@ -1111,6 +1112,7 @@ DEV void sg_parse_segment(const LzJob &job, SgLds *lds, const SgScratch &scr, ui
  * parsed, so it finds a hand-over.  Segment 0 starts from the state the previous
  * super-step ended in, every other one fresh.  In a redo round (phase 3 found a parser
  * that gave up) wave 0 parses on from that parser's exact state. */
+template <bool TABLE>
 DEV void sg_phase_parse(const LzJob &job, SgLds *lds, const SgScratch &scr, int w)
 {
     const uint32_t S0 = GUNI(lds->S0);
@@ -1150,7 +1152,7 @@ DEV void sg_phase_parse(const LzJob &job, SgLds *lds, const SgScratch &scr, int 
             }
         }
         SG_COUNT(2, redo ? 0x10000 + s : s);
-        sg_parse_segment(job, lds, scr, s, sp, slen, sat, (int)spend);
+        sg_parse_segment<TABLE>(job, lds, scr, s, sp, slen, sat, (int)spend);
         SG_COUNT(3, 0);
     }
 }

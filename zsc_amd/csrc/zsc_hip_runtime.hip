@@ -295,7 +295,8 @@ __global__ __launch_bounds__(64) void k_parse(const uint8_t *__restrict__ in,
 
 /* kernel 2 for long buffers at levels 4-9: SG_W wavefronts share one window and parse
  * SG_W segments of the same buffer at once (lz_parse_seg.h) */
-template <bool GENERIC> /* false: window_bits 15 / mem_level 8, their constants folded in */
+template <bool GENERIC, bool TABLE> /* GENERIC false: window_bits 15 / mem_level 8, their constants folded in;
+                                       TABLE: the plan has a match table (only with GENERIC false) */
 __global__ __launch_bounds__(SG_W * 64, SG_MIN_WAVES) void k_parse_seg(const uint8_t *__restrict__ in,
                                                          const ZdBuf *__restrict__ bufs,
                                                          const uint32_t *__restrict__ order,
@@ -376,7 +377,10 @@ __global__ __launch_bounds__(SG_W * 64, SG_MIN_WAVES) void k_parse_seg(const uin
                     stuck = true;
                     break;
                 }
-                sg_phase_parse(job, &lds, scr, w);
+                if (TABLE && job.r2 != nullptr)
+                    sg_phase_parse<true>(job, &lds, scr, w);
+                else
+                    sg_phase_parse<false>(job, &lds, scr, w);
                 __syncthreads();
                 sg_phase_resolve(job, &lds, scr, w);
                 __syncthreads();
@@ -1270,7 +1274,9 @@ extern "C" ZlibReturn zsc_hip_deflate_plan_run(zsc_hip_deflate_plan *pl, const v
                        (const uint16_t *)rank, (const uint16_t *)hib, tmp_syms, recs, pout,      \
                        (const ZdSched *)pl->d_sched.p, cfg, (uint32_t)(FIRST), (uint32_t)(COUNT))
             if (sb.cseg > 0) {
-                auto kern = (pl->wbits == 15 && pl->mem_level == 8) ? k_parse_seg<false> : k_parse_seg<true>;
+                auto kern = (pl->wbits == 15 && pl->mem_level == 8)
+                                ? (pl->use_table ? k_parse_seg<false, true> : k_parse_seg<false, false>)
+                                : k_parse_seg<true, false>;
                 hipLaunchKernelGGL(kern, dim3(sb.cseg), dim3(SG_W * 64), 0, st, in, bufs,
                                    (const uint32_t *)sb.d_order.p, (const uint32_t *)sorted,
                                    (const uint16_t *)rank, (const uint16_t *)hib,
