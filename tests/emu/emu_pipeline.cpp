@@ -20,8 +20,15 @@ struct uint4 { uint32_t x, y, z, w; };
  * record (segment | redo flag, batches) is appended to g_sg_log */
 extern "C" { unsigned long long g_sg_cnt[16]; unsigned g_sg_log[1 << 20]; unsigned g_sg_nlog; }
 static unsigned long long g_sg_mark;
+static int g_sg_in_fallback; /* [11]: candidate steps of walks done the reference's way after a staircase */
 static inline void sg_count(int what, unsigned n)
 {
+    if (what == 8)
+        g_sg_in_fallback = 1;
+    if (what == 5)
+        g_sg_in_fallback = 0; /* (a new search) */
+    if (what == 0 && g_sg_in_fallback)
+        g_sg_cnt[11] += n;
     if (what < 2 || what >= 4)
         g_sg_cnt[what] += n;
     else if (what == 2) {

@@ -14,6 +14,8 @@ data = corpus.make_buffer(kind, size, 1)
 cnt = (C.c_ulonglong * 16).in_dll(E, "g_sg_cnt"); log = (C.c_uint * (1 << 20)).in_dll(E, "g_sg_log")
 nlog = C.c_uint.in_dll(E, "g_sg_nlog")
 E.emu_set_seg_mode(2)
+E.emu_set_table(0)        # the product's defaults: no match table,
+E.emu_set_stair_min(256)  # chains of 256 entries or more searched as a staircase
 cap = size + (size >> 3) + 256
 out = C.create_string_buffer(cap); ol = C.c_uint32()
 E.emu_compress(data, size, level, 1, 0, out, cap, C.byref(ol))

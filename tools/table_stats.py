@@ -21,4 +21,4 @@ rc = E.emu_compress(data, size, level, 1, 0, out, cap, C.byref(ol))
 orc, want, _ = Oracle().compress(data, level)
 print(f"{kind} n={size} L{level}: stream {'==' if out.raw[:ol.value] == want else '!='} oracle ({ol.value} B)")
 print(f"  table: incomplete {mt[1]/max(1,mt[0]):.4f} of the entries; answering for longer prev_lengths too {mt[2]/max(1,mt[0]):.4f}")
-print(f"  parser: loop tops {sg[4]} ({sg[4]/size:.3f}/byte), hops {sg[7]} ({sg[7]/max(1,sg[4]):.3f} of them), searches {sg[5]}, batches {sg[0]} ({sg[0]/size:.3f}/byte), long compares {sg[1]}, walks done the reference's way {sg[8]}, lazy searches skipped (an empty chain) {sg[9]}, single look-ups in the table {sg[10]}")
+print(f"  parser: loop tops {sg[4]} ({sg[4]/size:.3f}/byte), hops {sg[7]} ({sg[7]/max(1,sg[4]):.3f} of them), searches {sg[5]}, batches {sg[0]} ({sg[0]/size:.3f}/byte), long compares {sg[1]}, walks done the reference's way {sg[8]} ({sg[11]} of the batches), lazy searches skipped (an empty chain) {sg[9]}, single look-ups in the table {sg[10]}")

@@ -77,6 +77,9 @@
 #ifndef SG_EMPTY_SKIP
 #define SG_EMPTY_SKIP 0 /* (measured: text and incompressible data lose 3-5 % to the test, the table class gains 4 %) a pending match and an empty chain among the trigrams a longer one must contain: no search */
 #endif
+#ifndef SG_FAR_OVER
+#define SG_FAR_OVER 128u /* the shortest chain in reach is longer than this: look at the far ones too */
+#endif
 #ifndef SG_STAIR_MIN
 #define SG_STAIR_MIN 256u /* chains at least this long are searched as a staircase (LzJob.stair_min) */
 #endif
@@ -863,7 +866,7 @@ DEV void sg_parse_segment(const LzJob &job, SgLds *lds, const SgScratch &scr, ui
                     int more = 1;
                     while (more) {
                         more = 0;
-                        uint32_t j = 0;
+                        uint32_t j = 0, cnj = 0, rhj = 0;
                         if (best >= 3u) {
                             /* the shortest chain among those whose lengths are in the register cache */
                             LANEVAR(uint32_t, tkey);
@@ -876,11 +879,32 @@ DEV void sg_parse_segment(const LzJob &job, SgLds *lds, const SgScratch &scr, ui
                                                ? (c & 0xffffu) + (c >> 16)
                                                : 0xffffffffu;
                             }
-                            const uint32_t tmin = GMIN_U32(tkey);
+                            uint32_t tmin = GMIN_U32(tkey);
                             FOR_GLANES { LV(ismin) = LV(tkey) == tmin; }
                             j = (uint32_t)CTZ64(GBALLOT(ismin)) - l0;
+                            /* A long match whose last trigrams lie beyond the cache (a run of equal bytes
+                             * and then something else: every chain in reach is the run's own, tens of
+                             * thousands of entries): the two chains that end at the byte which has to match
+                             * next are worth a trip to memory. */
+                            if (tmin > SG_FAR_OVER && l1 >= GRP) {
+                                for (uint32_t o = best - 3u; o <= best - 2u; o++) {
+                                    if (p + o - mt_at >= GRP && (uint64_t)p + o + 3u <= job.n) {
+                                        const uint32_t c = GUNI(job.cnt[p + o]);
+                                        const uint32_t t = (c & 0xffffu) + (c >> 16);
+                                        if (t < tmin) {
+                                            tmin = t;
+                                            j = o;
+                                            cnj = c;
+                                            rhj = GUNI((uint32_t)job.rank[p + o]) | (GUNI((uint32_t)job.hib[p + o]) << 16);
+                                        }
+                                    }
+                                }
+                            }
                         }
-                        const uint32_t cnj = GREADLANE(mcn, p + j - mt_at), rhj = GREADLANE(mrk, p + j - mt_at);
+                        if (p + j - mt_at < GRP) {
+                            cnj = GREADLANE(mcn, p + j - mt_at);
+                            rhj = GREADLANE(mrk, p + j - mt_at);
+                        }
                         const uint32_t nAj = cnj & 0xffffu, totj = nAj + (cnj >> 16);
                         const int32_t hiAj = (int32_t)(rhj & 0xffffu) - 1, hiBj = (int32_t)(rhj >> 16);
                         const uint32_t tileJ = (p + j) & ~ZD_TILE_MASK;
