@@ -70,6 +70,8 @@
 #endif
 #define SG_TRACE SG_G               /* positions a segment records (its own) */
 #define SG_TOKCAP (SG_G + SG_OV + 320u) /* tokens one segment's parser can emit */
+/* scratch of one workgroup in 32-bit words: SG_NS token areas, then SG_NS x SG_TRACE 16-bit token indices */
+#define SG_SCRATCH_WORDS (SG_NS * SG_TOKCAP + SG_NS * SG_TRACE / 2u)
 
 #ifndef SG_PICK_AHEAD
 #define SG_PICK_AHEAD 16u /* positions from p on whose chain lengths a search must find in the register cache */

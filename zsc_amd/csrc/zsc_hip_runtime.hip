@@ -295,8 +295,9 @@ __global__ __launch_bounds__(64) void k_parse(const uint8_t *__restrict__ in,
 
 /* kernel 2 for long buffers at levels 4-9: SG_W wavefronts share one window and parse
  * SG_W segments of the same buffer at once (lz_parse_seg.h) */
-template <bool GENERIC, bool TABLE> /* GENERIC false: window_bits 15 / mem_level 8, their constants folded in;
-                                       TABLE: the plan has a match table (only with GENERIC false) */
+template <bool GENERIC, bool TABLE, int LEVEL> /* GENERIC false: window_bits 15 / mem_level 8, their constants folded in;
+                                                  TABLE: the plan has a match table (only with GENERIC false);
+                                                  LEVEL 6: the default level's search parameters folded in too (0: any) */
 __global__ __launch_bounds__(SG_W * 64, SG_MIN_WAVES) void k_parse_seg(const uint8_t *__restrict__ in,
                                                          const ZdBuf *__restrict__ bufs,
                                                          const uint32_t *__restrict__ order,
@@ -309,7 +310,6 @@ __global__ __launch_bounds__(SG_W * 64, SG_MIN_WAVES) void k_parse_seg(const uin
                                                          ZdBlockRec *__restrict__ recs,
                                                          ZdParseOut *__restrict__ pout,
                                                          uint32_t *__restrict__ seg_tok,
-                                                         uint16_t *__restrict__ seg_sidx,
                                                          const ZdSched *__restrict__ sched,
                                                          const ZdLevel cfg, uint32_t stair_min,
                                                          uint32_t first, uint32_t nbuf)
@@ -340,14 +340,22 @@ __global__ __launch_bounds__(SG_W * 64, SG_MIN_WAVES) void k_parse_seg(const uin
         job.cfg.sym_cap = ZD_SYM_CAP;
         job.cfg.hbits = 15u;
     }
+    if (LEVEL == 6) { /* reference src/deflate.c:155: the fewer wave-uniform values the parser keeps, the fewer it spills */
+        job.cfg.good = 8;
+        job.cfg.lazy = 16;
+        job.cfg.nice = 128;
+        job.cfg.chain = 128;
+        job.cfg.slow = 1;
+    }
     job.strategy = buf.strategy;
     job.more = buf.more;
     job.sched = sched + buf.sched_off;
     job.nsched = buf.sched_n;
     job.n0 = buf.n0;
     SgScratch scr;
-    scr.tok = seg_tok + (uint64_t)blockIdx.x * (SG_NS * SG_TOKCAP);
-    scr.sidx = seg_sidx + (uint64_t)blockIdx.x * (SG_NS * SG_TRACE);
+    /* one area per workgroup: the segments' tokens, then their token indices (one pointer to keep) */
+    scr.tok = seg_tok + (uint64_t)blockIdx.x * SG_SCRATCH_WORDS;
+    scr.sidx = (uint16_t *)(scr.tok + SG_NS * SG_TOKCAP);
     const int w = (int)(threadIdx.x >> 6);
     sg_init(&lds, w);
     __syncthreads();
@@ -813,7 +821,7 @@ struct zsc_hip_deflate_plan {
     std::vector<SubBatch> subs;
     /* scratch shared by all sub-batches (sized for the largest) */
     DevBuf d_sorted, d_tmp_syms, d_rank, d_hib, d_cnt, d_dir, d_recs, d_plans, d_pout;
-    DevBuf d_seg_tok, d_seg_sidx; /* per long buffer: token staging of the segmented parser */
+    DevBuf d_seg_tok; /* per long buffer: token staging of the segmented parser (tokens, then token indices) */
     DevBuf d_r2; /* the match table (match_table.h): one entry per input position */
     bool use_table = false;
     uint32_t table_min = 0; /* buffers longer than this have a table (those the segmented parser takes) */
@@ -1141,12 +1149,11 @@ static ZlibReturn plan_create(zsc_hip_deflate_plan **plan_out, U32 count, const 
     for (const SubBatch &sb : pl->subs)
         max_seg = std::max<uint64_t>(max_seg, sb.cseg);
     if (pl->use_seg && max_seg) {
-        if (!pl->d_seg_tok.ensure(max_seg * SG_NS * SG_TOKCAP * 4ull) ||
-            !pl->d_seg_sidx.ensure(max_seg * SG_NS * SG_TRACE * 2ull)) {
+        if (!pl->d_seg_tok.ensure(max_seg * SG_SCRATCH_WORDS * 4ull)) {
             zsc_hip_deflate_plan_destroy(pl);
             return Z_MEM_ERROR;
         }
-        pl->scratch_bytes += pl->d_seg_tok.bytes + pl->d_seg_sidx.bytes;
+        pl->scratch_bytes += pl->d_seg_tok.bytes;
     }
 
     /* shared scratch: sorted (4 B/position), tmp aliased with the symbol stream
@@ -1275,14 +1282,15 @@ extern "C" ZlibReturn zsc_hip_deflate_plan_run(zsc_hip_deflate_plan *pl, const v
                        (const ZdSched *)pl->d_sched.p, cfg, (uint32_t)(FIRST), (uint32_t)(COUNT))
             if (sb.cseg > 0) {
                 auto kern = (pl->wbits == 15 && pl->mem_level == 8)
-                                ? (pl->use_table ? k_parse_seg<false, true> : k_parse_seg<false, false>)
-                                : k_parse_seg<true, false>;
+                                ? (pl->use_table ? k_parse_seg<false, true, 0>
+                                                 : pl->level == 6 ? k_parse_seg<false, false, 6> : k_parse_seg<false, false, 0>)
+                                : k_parse_seg<true, false, 0>;
                 hipLaunchKernelGGL(kern, dim3(sb.cseg), dim3(SG_W * 64), 0, st, in, bufs,
                                    (const uint32_t *)sb.d_order.p, (const uint32_t *)sorted,
                                    (const uint16_t *)rank, (const uint16_t *)hib,
                                    (const uint32_t *)cnt,
                                    pl->use_table ? (const uint32_t *)pl->d_r2.p : nullptr,                                    tmp_syms, recs,
-                                   pout, (uint32_t *)pl->d_seg_tok.p, (uint16_t *)pl->d_seg_sidx.p,
+                                   pout, (uint32_t *)pl->d_seg_tok.p,
                                    (const ZdSched *)pl->d_sched.p, cfg, pl->stair_min, 0u, sb.cseg);
             }
             if (pl->d_sched.p) { /* runs with joints: the parsers keep a hole map (lz_parse.h) */
@@ -1407,7 +1415,6 @@ extern "C" void zsc_hip_deflate_plan_destroy(zsc_hip_deflate_plan *pl)
     pl->d_hib.release();
     pl->d_cnt.release();
     pl->d_seg_tok.release();
-    pl->d_seg_sidx.release();
     pl->d_r2.release();
     pl->d_sched.release();
     pl->d_dir.release();
