@@ -30,6 +30,7 @@
 #include "zsc_dev.h"
 
 #define LZ_PR 512u /* positions covered by the rank/hib look-ahead ring */
+#define LZ_MIRROR 512u /* bytes of the window ring's start kept a second time behind its end */
 #define LZ_PR_FAST 128u /* the same in the greedy parser's LDS */
 
 /* LDS of the lazy parser (levels 4-9): 36 KiB window ring + look-ahead rings = 39 680 B,
@@ -41,7 +42,7 @@ struct LzLdsT {
     static constexpr bool HOLES = WITH_HOLES;
     static constexpr bool GLOBAL_WIN = false; /* the window is the LDS ring */
     static constexpr uint32_t PR = LZ_PR;
-    uint8_t ring[RING + 512]; /* sliding window; first 16 bytes mirrored after the end, rest slack for masked over-reads */
+    uint8_t ring[RING + 512]; /* sliding window; the first LZ_MIRROR bytes mirrored after the end, rest slack for masked over-reads */
     uint32_t stage[WAVE];     /* symbols waiting for a coalesced store */
     uint16_t prank[LZ_PR];    /* rank[] of the next few hundred positions */
     uint16_t phib[LZ_PR];     /* hib[] of the same positions */
@@ -206,10 +207,15 @@ DEV void lz_load_chunk(const LzJob &job, L *lds, LzState &st)
     }
     WAVE_SYNC();
     if (r0 == 0 && !L::GLOBAL_WIN) {
-        FOR_LANES
-        {
-            if (LANE < 16)
-                lds->ring[L::RING + LANE] = lds->ring[LANE];
+        /* the first LZ_MIRROR bytes again behind the end: a string that starts inside the ring is
+         * read with linear indices, whatever its length (at most MAX_MATCH and a few bytes) */
+        for (uint32_t k = 0; k < LZ_MIRROR; k += 4u * WAVE) {
+            FOR_LANES
+            {
+                const uint32_t o = k + 4u * (uint32_t)LANE;
+                if (o < LZ_MIRROR)
+                    *(uint32_t *)&lds->ring[L::RING + o] = *(const uint32_t *)&lds->ring[o];
+            }
         }
     }
     WAVE_SYNC();

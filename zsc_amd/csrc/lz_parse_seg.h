@@ -85,6 +85,9 @@
 #ifndef SG_STAIR_MIN
 #define SG_STAIR_MIN 256u /* chains at least this long are searched as a staircase (LzJob.stair_min) */
 #endif
+#ifndef SG_ONE
+#define SG_ONE 1 /* 0: chains that fit one load are walked like the others */
+#endif
 #ifndef SG_STAIR
 #define SG_STAIR 1 /* 0: every search is the reference's walk along p's own chain (the parser as it was) */
 #endif
@@ -213,6 +216,8 @@ DEV void sg_phase_begin(const LzJob &job, SgLds *lds, int w)
 
 /* four bytes of the window as a wave-uniform value */
 #define SG_PEEK32(pos, out) ((out) = GUNI(lds_u32(lds->ring, lz_ridx<L>(st, (pos)))))
+/* ... at p + OFF (OFF below LZ_MIRROR): rp is p's place in the ring, and what follows it there is linear */
+#define SG_PEEKP(OFF, out) ((out) = GUNI(lds_u32(lds->ring, rp + (OFF))))
 
 /* entries of candidates 64*B .. 64*B+63; lanes past the end of the chain read entry 0 of
  * the tile (a valid address) and are masked later -- cheaper than predicating the load */
@@ -225,14 +230,21 @@ DEV void sg_phase_begin(const LzJob &job, SgLds *lds, int w)
         LV(E) = runA[_i];                                                                     \
     }
 
+/* the string at p, four bytes a lane (dword l = bytes 4l .. 4l+3) */
+#define SG_PV_LOAD()                                                                          \
+    do {                                                                                      \
+        if (pv_at != p) {                                                                     \
+            pv_at = p;                                                                        \
+            FOR_GLANES { LV(pv) = lds_u32(lds->ring, rp + 4u * (uint32_t)GLANE); }             \
+        }                                                                                     \
+    } while (0)
+
 /* cooperative longest common prefix of the strings at QJ and p (at most cap bytes) */
 #define SG_LCP(QJ, LEN)                                                                       \
     do {                                                                                      \
         SG_COUNT(1, 1);                                                                       \
-        if (pv_at != p) {                                                                     \
-            pv_at = p;                                                                        \
-            FOR_GLANES { LV(pv) = lds_u32(lds->ring, lz_ridx<L>(st, p + 4u * (uint32_t)GLANE)); } \
-        }                                                                                     \
+        SG_PV_LOAD();                                                                         \
+        const uint32_t _rq = lz_ridx<L>(st, (QJ)); /* (the ring is linear from there: LZ_MIRROR) */ \
         if (4u * GRP >= 256u) {                                                               \
             /* a 64-lane group: the first 256 bytes in one step, against the string at p held \
              * in registers, then the last two bytes one by one */                            \
@@ -240,7 +252,7 @@ DEV void sg_phase_begin(const LzJob &job, SgLds *lds, int w)
             LANEVAR(int, _differs);                                                           \
             FOR_GLANES                                                                        \
             {                                                                                 \
-                LV(_diff) = lds_u32(lds->ring, lz_ridx<L>(st, (QJ) + 4u * (uint32_t)GLANE)) ^ LV(pv); \
+                LV(_diff) = lds_u32(lds->ring, _rq + 4u * (uint32_t)GLANE) ^ LV(pv);          \
                 LV(_differs) = LV(_diff) != 0;                                                \
             }                                                                                 \
             const uint64_t _dm = GBALLOT(_differs);                                           \
@@ -249,11 +261,13 @@ DEV void sg_phase_begin(const LzJob &job, SgLds *lds, int w)
                 (LEN) = 4u * (uint32_t)_f + ((uint32_t)CTZ32(GREADLANE(_diff, _f)) >> 3);     \
             } else {                                                                          \
                 (LEN) = 256;                                                                  \
-                if (cap > 256 && GUNI(lds->ring[lz_ridx<L>(st, (QJ) + 256)]) ==               \
-                                     GUNI(lds->ring[lz_ridx<L>(st, p + 256)])) {              \
+                /* (rare: nothing of this is worked out ahead of the loops around it) */      \
+                uint32_t _rp = rp, _cap = cap;                                                \
+                OPAQUE_UNI(_rp);                                                              \
+                OPAQUE_UNI(_cap);                                                             \
+                if (_cap > 256 && GUNI(lds->ring[_rq + 256]) == GUNI(lds->ring[_rp + 256])) { \
                     (LEN) = 257;                                                              \
-                    if (cap > 257 && GUNI(lds->ring[lz_ridx<L>(st, (QJ) + 257)]) ==           \
-                                         GUNI(lds->ring[lz_ridx<L>(st, p + 257)]))            \
+                    if (_cap > 257 && GUNI(lds->ring[_rq + 257]) == GUNI(lds->ring[_rp + 257])) \
                         (LEN) = 258;                                                          \
                 }                                                                             \
             }                                                                                 \
@@ -266,8 +280,8 @@ DEV void sg_phase_begin(const LzJob &job, SgLds *lds, int w)
                 FOR_GLANES                                                                    \
                 {                                                                             \
                     const uint32_t _pw = _o == 0u ? LV(pv)                                    \
-                                                  : lds_u32(lds->ring, lz_ridx<L>(st, p + _o + 4u * (uint32_t)GLANE)); \
-                    LV(_diff) = lds_u32(lds->ring, lz_ridx<L>(st, (QJ) + _o + 4u * (uint32_t)GLANE)) ^ _pw; \
+                                                  : lds_u32(lds->ring, rp + _o + 4u * (uint32_t)GLANE); \
+                    LV(_diff) = lds_u32(lds->ring, _rq + _o + 4u * (uint32_t)GLANE) ^ _pw;    \
                     LV(_differs) = LV(_diff) != 0;                                            \
                 }                                                                             \
                 const uint64_t _dm = GBALLOT(_differs);                                       \
@@ -400,7 +414,7 @@ DEV void sg_phase_begin(const LzJob &job, SgLds *lds, int w)
                 break;                                                                        \
             }                                                                                 \
             if (_improved) {                                                                  \
-                SG_PEEK32(p + best - 1, sb);                                                  \
+                SG_PEEKP(best - 1u, sb);                                                  \
                 sb &= 0xffffu;                                                                \
                 FOR_GLANES                                                                     \
                 {                                                                             \
@@ -416,6 +430,85 @@ DEV void sg_phase_begin(const LzJob &job, SgLds *lds, int w)
         }                                                                                     \
         if (_m_dead != 0 && !fin)                                                             \
             fin = 1; /* the chain leaves the window (:1519) */                                \
+    } while (0)
+
+/* A chain that fits ONE load and is shorter than the chain budget -- four searches in five on text.
+ * The budget cannot run out, so the walk (src/deflate.c:1455-1519) ends in: the first candidate that
+ * reaches nice_match if there is one, otherwise the longest one, the nearest of them first.  Every
+ * lane works out its own candidate's length, four bytes a step against the string at p (a step is
+ * one instruction stream for all 64 of them, where the walk spends a long compare per candidate that
+ * passes the pre-check); when one candidate is left after the first eight bytes the whole wave
+ * compares the rest of it at once.  Sets best / where; `bail`: two candidates agree with p for more
+ * than 4 GRP bytes, the walk below takes over. */
+#define SG_EVAL_ONE()                                                                         \
+    do {                                                                                      \
+        LANEVAR(uint32_t, _q);                                                                \
+        LANEVAR(uint32_t, _r);                                                                \
+        LANEVAR(uint32_t, _len);                                                              \
+        LANEVAR(int, _act);                                                                   \
+        SG_COUNT(12, 1);                                                                      \
+        SG_PV_LOAD();                                                                         \
+        FOR_GLANES                                                                             \
+        {                                                                                     \
+            const uint32_t _v = (uint32_t)GLANE;                                               \
+            const uint32_t q = tileA + (LV(e0) & ZD_TILE_MASK) - (_v < nA ? 0u : ZD_TILE);    \
+            const int live = _v == 0 || (_v < total && q > floor_pos); /* :1519 */            \
+            const uint32_t r = live ? lz_ridx<L>(st, q) : 0u;                                 \
+            const uint32_t x = lds_u32(lds->ring, r) ^ s0123;                                 \
+            const int m3 = live && (x & 0xffffffu) == 0u;                                     \
+            LV(_q) = q;                                                                       \
+            LV(_r) = r;                                                                       \
+            LV(_len) = m3 ? (x == 0u ? 4u : 3u) : 0u;                                         \
+            LV(_act) = m3 && x == 0u;                                                         \
+        }                                                                                     \
+        uint64_t _am = GBALLOT(_act);                                                          \
+        uint32_t _k = 1;                                                                      \
+        while (_am != 0 && 4u * _k < cap) {                                                   \
+            if (_k >= GRP) {                                                                  \
+                bail = 1;                                                                     \
+                break;                                                                        \
+            }                                                                                 \
+            if (_k >= 2u && (_am & (_am - 1ull)) == 0) {                                      \
+                const int _j = CTZ64(_am);                                                    \
+                const uint32_t _qj = GREADLANE(_q, _j);                                        \
+                uint32_t _l;                                                                  \
+                SG_LCP(_qj, _l);                                                              \
+                FOR_GLANES                                                                     \
+                {                                                                             \
+                    if (GLANE == _j)                                                           \
+                        LV(_len) = _l;                                                        \
+                }                                                                             \
+                break;                                                                        \
+            }                                                                                 \
+            const uint32_t _pk = GREADLANE(pv, _k);                                            \
+            FOR_GLANES                                                                         \
+            {                                                                                 \
+                if (LV(_act)) {                                                               \
+                    const uint32_t d = lds_u32(lds->ring, LV(_r) + 4u * _k) ^ _pk;            \
+                    LV(_len) = d ? 4u * _k + ((uint32_t)CTZ32(d) >> 3) : 4u * _k + 4u;        \
+                    LV(_act) = d == 0u;                                                       \
+                }                                                                             \
+            }                                                                                 \
+            _am = GBALLOT(_act);                                                               \
+            _k++;                                                                             \
+        }                                                                                     \
+        if (!bail) {                                                                          \
+            LANEVAR(uint32_t, _key);                                                          \
+            LANEVAR(int, _nice);                                                              \
+            FOR_GLANES                                                                         \
+            {                                                                                 \
+                const uint32_t l = LV(_len) < cap ? LV(_len) : cap;                           \
+                LV(_nice) = l >= nice;                                                        \
+                LV(_key) = ((511u - l) << 8) | (uint32_t)GLANE; /* longest first, then nearest */ \
+            }                                                                                 \
+            const uint64_t _mn = GBALLOT(_nice);                                               \
+            const uint32_t _kk = _mn ? GREADLANE(_key, CTZ64(_mn)) : GMIN_U32(_key);           \
+            const uint32_t _l = 511u - (_kk >> 8);                                            \
+            if (_l > best) {                                                                  \
+                best = _l;                                                                    \
+                where = GREADLANE(_q, _kk & 0xffu);                                            \
+            }                                                                                 \
+        }                                                                                     \
     } while (0)
 
 /* four window positions at once: which of the 16-bit strings at byte offsets 0..3 of the
@@ -504,7 +597,7 @@ DEV void sg_phase_begin(const LzJob &job, SgLds *lds, int w)
                     }                                                                         \
                     if (_moved) {                                                             \
                         /* new best_len: other bytes at another offset from here on */        \
-                        SG_PEEK32(p + best - 1, sb);                                          \
+                        SG_PEEKP(best - 1u, sb);                                          \
                         sb &= 0xffffu;                                                        \
                         _qn = _qj - 1u;                                                       \
                         break;                                                                \
@@ -755,8 +848,9 @@ DEV void sg_parse_segment(const LzJob &job, SgLds *lds, const SgScratch &scr, ui
                 continue;
             }
         }
+        const uint32_t rp = lz_ridx<L>(st, p);
         uint32_t s0123;
-        SG_PEEK32(p, s0123);
+        SG_PEEKP(0u, s0123);
         const uint32_t prev_len = cur_len, prev_at = cur_at;
         cur_len = 2;
         /* no hop, but the table may still know this one search: the entry itself when no match is
@@ -821,6 +915,22 @@ DEV void sg_parse_segment(const LzJob &job, SgLds *lds, const SgScratch &scr, ui
                 LANEVAR(uint32_t, f2);
                 LANEVAR(uint32_t, f3);
                 SG_LOAD(e0, 0u);
+                int bail = 0, searched = 0;
+                if (SG_ONE && job.cfg.hbits == 15u && total <= GRP && total < budget && best < look) {
+                    const uint32_t ent0 = GREADLANE(e0, 0);
+                    const uint32_t q0 = tileA + (ent0 & ZD_TILE_MASK) - (nA ? 0u : ZD_TILE);
+                    /* the chain head may lie at exactly MAX_DIST (:2032), later links may not */
+                    if (q0 > st.base && p - q0 <= job.cfg.max_dist) {
+                        SG_EVAL_ONE();
+                        head_seen = !bail;
+                        if (bail) {
+                            best = prev_len;
+                            where = cur_at;
+                        }
+                    }
+                    searched = !bail;
+                }
+                if (!searched) {
                 /* a long chain is searched as a staircase over shorter ones (below); a short one is
                  * walked as the reference walks it, 64 candidates a step */
                 const int stair = SG_STAIR && job.cfg.hbits == 15u && total >= job.stair_min;
@@ -849,7 +959,7 @@ DEV void sg_parse_segment(const LzJob &job, SgLds *lds, const SgScratch &scr, ui
                     if (best <= 3u) /* the two bytes are among the four read at p */
                         sb = (s0123 >> (8u * (best - 1u))) & 0xffffu;
                     else {
-                        SG_PEEK32(p + best - 1, sb);
+                        SG_PEEKP(best - 1u, sb);
                         sb &= 0xffffu;
                     }
                 }
@@ -918,9 +1028,9 @@ DEV void sg_parse_segment(const LzJob &job, SgLds *lds, const SgScratch &scr, ui
                         uint32_t sb4 = 0, smid = 0;
                         const uint32_t omid = best >= 8u ? best / 2u : 0u;
                         if (best >= 3u) {
-                            SG_PEEK32(p + best - 3u, sb4);
+                            SG_PEEKP(best - 3u, sb4);
                             if (omid)
-                                SG_PEEK32(p + omid, smid);
+                                SG_PEEKP(omid, smid);
                         }
                         int found = 0, gone = 0;
                         for (uint32_t bb = 0; bb * GRP < totj && !found && !gone; bb++) {
@@ -1026,7 +1136,7 @@ DEV void sg_parse_segment(const LzJob &job, SgLds *lds, const SgScratch &scr, ui
                             if (best <= 3u)
                                 sb = (s0123 >> (8u * (best - 1u))) & 0xffffu;
                             else {
-                                SG_PEEK32(p + best - 1, sb);
+                                SG_PEEKP(best - 1u, sb);
                                 sb &= 0xffffu;
                             }
                         }
@@ -1074,6 +1184,7 @@ DEV void sg_parse_segment(const LzJob &job, SgLds *lds, const SgScratch &scr, ui
                         }
                     }
                 }
+                } /* (!searched) */
                 if (head_seen) {
                     cur_at = where;
                     cur_len = best < look ? best : look;

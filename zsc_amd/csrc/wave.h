@@ -135,6 +135,7 @@ static inline uint32_t emu_brev32(uint32_t v)
 #define COPY16(dst, src) memcpy((dst), (src), 16)
 #define RCP_F32(x) (1.0f / (x))
 #define UNI(x) (x)
+#define OPAQUE_UNI(x) ((void)0)
 
 #else
 /* ---------------------------------------------------------------- gfx950 */
@@ -194,14 +195,24 @@ DEV uint64_t wave_sum_u64(uint64_t v)
 }
 #define WAVE_SUM(in) wave_sum_u64(in)
 
+/* The smallest value over the 64 lanes, on the data-parallel-primitive path of the vector ALU
+ * (six v_min_u32 with a DPP operand and one v_readlane) instead of six trips through LDS
+ * (ds_bpermute): within quads, within rows of 16, then lane 15 of a row into the next row and
+ * lane 31 into the upper half, so that lane 63 holds the result. */
+#define WAVE_DPP_MIN_STEP(v, ctrl, rows)                                                              \
+    do {                                                                                              \
+        const uint32_t _o = (uint32_t)__builtin_amdgcn_update_dpp((int)(v), (int)(v), (ctrl), (rows), 0xf, false); \
+        (v) = _o < (v) ? _o : (v);                                                                    \
+    } while (0)
 DEV uint32_t wave_min_u32(uint32_t v)
 {
-#pragma unroll
-    for (int d = 32; d >= 1; d >>= 1) {
-        const uint32_t o = (uint32_t)__shfl_xor((int)v, d);
-        v = o < v ? o : v;
-    }
-    return (uint32_t)__builtin_amdgcn_readfirstlane((int)v);
+    WAVE_DPP_MIN_STEP(v, 0xb1, 0xf);  /* quad_perm [1,0,3,2] */
+    WAVE_DPP_MIN_STEP(v, 0x4e, 0xf);  /* quad_perm [2,3,0,1] */
+    WAVE_DPP_MIN_STEP(v, 0x141, 0xf); /* row_half_mirror */
+    WAVE_DPP_MIN_STEP(v, 0x140, 0xf); /* row_mirror: every lane of a row holds the row's minimum */
+    WAVE_DPP_MIN_STEP(v, 0x142, 0xa); /* row_bcast:15 into rows 1 and 3 */
+    WAVE_DPP_MIN_STEP(v, 0x143, 0xc); /* row_bcast:31 into rows 2 and 3 */
+    return (uint32_t)__builtin_amdgcn_readlane((int)v, 63);
 }
 #define WAVE_MIN_U32(in) wave_min_u32(in)
 
@@ -245,6 +256,10 @@ DEV uint32_t lds_u32(const uint8_t *base, uint32_t idx)
  * branches on it are scalar branches instead of exec-mask regions and arithmetic on
  * it runs on the scalar unit. */
 #define UNI(x) ((uint32_t)__builtin_amdgcn_readfirstlane((int)(x)))
+/* A wave-uniform value the compiler may not reason about from here on (no instruction): what is
+ * computed from it stays in the rarely taken branch it is needed in, instead of being hoisted out
+ * of the loops around it and paid for on every trip. */
+#define OPAQUE_UNI(x) asm volatile("" : "+s"(x))
 /* both sides 16-byte aligned: one global_load_dwordx4 + one ds_write_b128 */
 #define COPY16(dst, src) (*(uint4 *)(dst) = *(const uint4 *)(src))
 #define RCP_F32(x) __builtin_amdgcn_rcpf(x) /* v_rcp_f32: 1 ulp */
