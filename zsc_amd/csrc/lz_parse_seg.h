@@ -563,6 +563,17 @@ DEV void sg_phase_begin(const LzJob &job, SgLds *lds, int w)
                     const uint32_t _hj = _rtop - _x >= 15u ? 15u : _rtop - _x;                \
                     const uint32_t _lj = _rlo > _x ? _rlo - _x : 0u;                          \
                     _m &= ((2u << _hj) - 1u) & ~((1u << _lj) - 1u);                           \
+                    /* of those, the ones that start with p's three bytes (every lane goes through \
+                     * its own few at the same time; the wave then visits what is left, in order); \
+                     * not where they come thick -- a run of one byte: they all do */            \
+                    uint32_t _left = POPC64((uint64_t)_m) <= 4 ? _m : 0u;                     \
+                    while (_left != 0) {                                                      \
+                        const uint32_t _b = (uint32_t)CTZ32(_left);                           \
+                        _left &= _left - 1u;                                                  \
+                        const uint32_t _t3 = lds_u32(lds->ring, lz_ridx<L>(st, _x + _b - _off)); \
+                        if (((_t3 ^ s0123) & 0xffffffu) != 0)                                 \
+                            _m &= ~(1u << _b);                                                \
+                    }                                                                         \
                 }                                                                             \
                 LV(_m16) = _m;                                                                \
                 LV(_has) = _m != 0;                                                           \
