@@ -432,6 +432,27 @@ DEV void sg_phase_begin(const LzJob &job, SgLds *lds, int w)
             fin = 1; /* the chain leaves the window (:1519) */                                \
     } while (0)
 
+/* Lanes with ACT set hold a candidate (ring index R) whose first four bytes are p's: every such lane
+ * compares on, four bytes a step against the string at p (pv), for at most KLIM dwords in all.
+ * LEN becomes the length of the common prefix (possibly beyond cap: the caller cuts it); a lane
+ * still equal after 4 KLIM bytes keeps ACT set and LEN at that lower bound. */
+#define SG_LANE_LCP(ACT, R, LEN, KLIM)                                                        \
+    do {                                                                                      \
+        uint64_t _am = GBALLOT(ACT);                                                           \
+        for (uint32_t _k = 1; _am != 0 && _k < (KLIM) && 4u * _k < cap; _k++) {               \
+            const uint32_t _pk = GREADLANE(pv, _k);                                            \
+            FOR_GLANES                                                                         \
+            {                                                                                 \
+                if (LV(ACT)) {                                                                \
+                    const uint32_t d = lds_u32(lds->ring, LV(R) + 4u * _k) ^ _pk;             \
+                    LV(LEN) = d ? 4u * _k + ((uint32_t)CTZ32(d) >> 3) : 4u * _k + 4u;         \
+                    LV(ACT) = d == 0u;                                                        \
+                }                                                                             \
+            }                                                                                 \
+            _am = GBALLOT(ACT);                                                                \
+        }                                                                                     \
+    } while (0)
+
 /* A chain that fits ONE load and is shorter than the chain budget -- four searches in five on text.
  * The budget cannot run out, so the walk (src/deflate.c:1455-1519) ends in: the first candidate that
  * reaches nice_match if there is one, otherwise the longest one, the nearest of them first.  Every
@@ -1048,6 +1069,9 @@ DEV void sg_parse_segment(const LzJob &job, SgLds *lds, const SgScratch &scr, ui
                             LANEVAR(uint32_t, ej);
                             LANEVAR(uint32_t, _q);
                             LANEVAR(uint32_t, _w0);
+                            LANEVAR(uint32_t, _r);
+                            LANEVAR(uint32_t, _len);
+                            LANEVAR(int, _act);
                             LANEVAR(int, _pass);
                             LANEVAR(int, _gone);
                             if (j == 0u && bb == 0u) {
@@ -1085,6 +1109,7 @@ DEV void sg_parse_segment(const LzJob &job, SgLds *lds, const SgScratch &scr, ui
                                 }
                                 LV(_q) = q;
                                 LV(_w0) = w0;
+                                LV(_r) = r0;
                                 LV(_gone) = g;
                                 LV(_pass) = ok;
                             }
@@ -1094,28 +1119,57 @@ DEV void sg_parse_segment(const LzJob &job, SgLds *lds, const SgScratch &scr, ui
                                 todo &= (mgone & (0ull - mgone)) - 1ull; /* what comes after the first such entry is older still */
                                 gone = 1;
                             }
+                            if (todo != 0) {
+                                /* the lengths of all of them at once (the first 32 bytes; what agrees with p
+                                 * beyond that gets the wave's long compare when its turn comes), then the steps
+                                 * this load holds, one after the other: each the nearest entry longer than best */
+                                FOR_GLANES
+                                {
+                                    const int t = (int)((todo >> GLANE) & 1ull);
+                                    const int four = t && cap > 3u && LV(_w0) == s0123;
+                                    LV(_len) = t ? (four ? 4u : 3u) : 0u;
+                                    LV(_act) = four;
+                                }
+                                SG_PV_LOAD();
+                                SG_LANE_LCP(_act, _r, _len, 8u);
+                            }
                             while (todo != 0) {
+                                LANEVAR(int, _imp);
+                                FOR_GLANES { LV(_imp) = LV(_act) || (LV(_len) < cap ? LV(_len) : cap) > best; }
+                                todo &= GBALLOT(_imp);
+                                if (todo == 0)
+                                    break;
                                 const int jl = CTZ64(todo);
                                 const uint32_t qx = GREADLANE(_q, jl);
-                                uint32_t len = 3;
-                                if (cap > 3u && GREADLANE(_w0, jl) == s0123)
+                                uint32_t len = GREADLANE(_len, jl);
+                                if ((GBALLOT(_act) >> jl) & 1ull) {
                                     SG_LCP(qx, len);
+                                    FOR_GLANES
+                                    {
+                                        if (GLANE == jl) {
+                                            LV(_act) = 0;
+                                            LV(_len) = len;
+                                        }
+                                    }
+                                }
+                                if (len > cap)
+                                    len = cap;
                                 if (len > best) {
                                     found = 1;
                                     where = qx;
                                     best = len;
                                     bnd = qx;
                                     nrec++;
-                                    break;
+                                    if (qs == 0xffffffffu && best >= 5u)
+                                        qs = where;
+                                    if (best >= nice)
+                                        break;
                                 }
-                                todo &= todo - 1ull;
+                                todo &= ~((2ull << jl) - 1ull);
                             }
                         }
-                        if (found && best < nice) {
+                        if (found && best < nice)
                             more = 1;
-                            if (qs == 0xffffffffu && best >= 5u)
-                                qs = where;
-                        }
                     }
                     fin = 1;
                     if (nrec != 0) {
