@@ -453,7 +453,8 @@ DEV void sg_phase_begin(const LzJob &job, SgLds *lds, int w)
         }                                                                                     \
     } while (0)
 
-/* A chain that fits ONE load and is shorter than the chain budget -- four searches in five on text.
+/* A chain of at most four loads that is shorter than the chain budget -- two searches in three on text;
+ * this is one load of it (entries E, number B).
  * The budget cannot run out, so the walk (src/deflate.c:1455-1519) ends in: the first candidate that
  * reaches nice_match if there is one, otherwise the longest one, the nearest of them first.  Every
  * lane works out its own candidate's length, four bytes a step against the string at p (a step is
@@ -461,7 +462,7 @@ DEV void sg_phase_begin(const LzJob &job, SgLds *lds, int w)
  * passes the pre-check); when one candidate is left after the first eight bytes the whole wave
  * compares the rest of it at once.  Sets best / where; `bail`: two candidates agree with p for more
  * than 4 GRP bytes, the walk below takes over. */
-#define SG_EVAL_ONE()                                                                         \
+#define SG_EVAL_ONE(E, B)                                                                        \
     do {                                                                                      \
         LANEVAR(uint32_t, _q);                                                                \
         LANEVAR(uint32_t, _r);                                                                \
@@ -471,8 +472,8 @@ DEV void sg_phase_begin(const LzJob &job, SgLds *lds, int w)
         SG_PV_LOAD();                                                                         \
         FOR_GLANES                                                                             \
         {                                                                                     \
-            const uint32_t _v = (uint32_t)GLANE;                                               \
-            const uint32_t q = tileA + (LV(e0) & ZD_TILE_MASK) - (_v < nA ? 0u : ZD_TILE);    \
+            const uint32_t _v = (B)*GRP + (uint32_t)GLANE;                                     \
+            const uint32_t q = tileA + (LV(E) & ZD_TILE_MASK) - (_v < nA ? 0u : ZD_TILE);     \
             const int live = _v == 0 || (_v < total && q > floor_pos); /* :1519 */            \
             const uint32_t r = live ? lz_ridx<L>(st, q) : 0u;                                 \
             const uint32_t x = lds_u32(lds->ring, r) ^ s0123;                                 \
@@ -948,12 +949,27 @@ DEV void sg_parse_segment(const LzJob &job, SgLds *lds, const SgScratch &scr, ui
                 LANEVAR(uint32_t, f3);
                 SG_LOAD(e0, 0u);
                 int bail = 0, searched = 0;
-                if (SG_ONE && job.cfg.hbits == 15u && total <= GRP && total < budget && best < look) {
+                if (SG_ONE && job.cfg.hbits == 15u && total <= 4u * GRP && total < budget && best < look) {
+                    if (total > GRP) {
+                        SG_LOAD(e1, 1u);
+                        if (total > 2u * GRP) {
+                            SG_LOAD(e2, 2u);
+                            SG_LOAD(e3, 3u);
+                        }
+                    }
                     const uint32_t ent0 = GREADLANE(e0, 0);
                     const uint32_t q0 = tileA + (ent0 & ZD_TILE_MASK) - (nA ? 0u : ZD_TILE);
                     /* the chain head may lie at exactly MAX_DIST (:2032), later links may not */
                     if (q0 > st.base && p - q0 <= job.cfg.max_dist) {
-                        SG_EVAL_ONE();
+                        SG_EVAL_ONE(e0, 0u);
+                        if (!bail && best < nice && total > GRP) {
+                            SG_EVAL_ONE(e1, 1u);
+                            if (!bail && best < nice && total > 2u * GRP) {
+                                SG_EVAL_ONE(e2, 2u);
+                                if (!bail && best < nice && total > 3u * GRP)
+                                    SG_EVAL_ONE(e3, 3u);
+                            }
+                        }
                         head_seen = !bail;
                         if (bail) {
                             best = prev_len;
