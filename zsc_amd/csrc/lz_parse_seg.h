@@ -933,7 +933,8 @@ DEV void sg_parse_segment(const LzJob &job, SgLds *lds, const SgScratch &scr, ui
                 const int32_t hiA = (int32_t)(rh & 0xffffu) - 1, hiB = (int32_t)(rh >> 16);
                 const uint32_t tileA = p & ~ZD_TILE_MASK;
                 const uint32_t *runA = job.sorted + (uint64_t)(p >> 15) * ZD_TILE;
-                uint32_t floor_pos = p - st.base > job.cfg.max_dist ? p - job.cfg.max_dist : st.base;
+                const uint32_t far = p - st.base > job.cfg.max_dist;
+                uint32_t floor_pos = far ? p - job.cfg.max_dist : st.base;
                 const uint32_t cap = look < 258u ? look : 258u;
                 const uint32_t nice = job.cfg.nice < look ? job.cfg.nice : look;
                 uint32_t best = prev_len, where = cur_at, sb = 0;
@@ -949,7 +950,9 @@ DEV void sg_parse_segment(const LzJob &job, SgLds *lds, const SgScratch &scr, ui
                 LANEVAR(uint32_t, f3);
                 SG_LOAD(e0, 0u);
                 int bail = 0, searched = 0;
-                if (SG_ONE && job.cfg.hbits == 15u && total <= 4u * GRP && total < budget && best < look) {
+                /* (one comparison: the chain is shorter than the budget and than four loads, and there is room for a longer match) */
+                const uint32_t one_lim = best < look ? (budget < 4u * GRP + 1u ? budget : 4u * GRP + 1u) : 0u;
+                if (SG_ONE && job.cfg.hbits == 15u && total < one_lim) {
                     if (total > GRP) {
                         SG_LOAD(e1, 1u);
                         if (total > 2u * GRP) {
@@ -959,8 +962,9 @@ DEV void sg_parse_segment(const LzJob &job, SgLds *lds, const SgScratch &scr, ui
                     }
                     const uint32_t ent0 = GREADLANE(e0, 0);
                     const uint32_t q0 = tileA + (ent0 & ZD_TILE_MASK) - (nA ? 0u : ZD_TILE);
-                    /* the chain head may lie at exactly MAX_DIST (:2032), later links may not */
-                    if (q0 > st.base && p - q0 <= job.cfg.max_dist) {
+                    /* the chain head may lie at exactly MAX_DIST (:2032), later links may not:
+                     * q0 > base and p - q0 <= MAX_DIST, as one comparison */
+                    if (q0 > floor_pos - far) {
                         SG_EVAL_ONE(e0, 0u);
                         if (!bail && best < nice && total > GRP) {
                             SG_EVAL_ONE(e1, 1u);
