@@ -1,6 +1,7 @@
 """Seeded soak of the GPU paths against the oracle (the checker): random sizes, data classes, levels,
 wrappers, window_bits, mem_level, strategies, section lengths and dest capacities, many streams per
-batched call; the oracle runs on the host cores beside it.  usage: soak.py SECONDS [SEED]"""
+batched call; the oracle runs on the host cores beside it.  usage: soak.py SECONDS [SEED]
+(SOAK_BIG=1: few long streams per batch; SOAK_VERBOSE=1: a line per batch before it runs)"""
 import os, sys, time, random
 from concurrent.futures import ProcessPoolExecutor
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
@@ -75,6 +76,10 @@ def main():
             bound = o.max_output(n, mbl, lvl, wb, ml)[1]
             cap = rnd.choice([bound, bound, bound, bound + 77, max(1, bound // 2), max(1, bound // 9)])
             jobs.append((kind, n, rnd.randrange(1 << 30), lvl, wb, ml, strat, mbl, cap))
+        if os.environ.get("SOAK_VERBOSE"):
+            print(f"batch {batches}: level {lvl} wb {wb} mem_level {ml} strategy {strat} sections {sections} "
+                  f"{len(jobs)} streams {sum(j[1] for j in jobs) / 1e6:.1f} MB at {time.time() - t0:.0f}s: "
+                  + " ".join(f"{j[0]}:{j[1]}/{j[7]}" for j in jobs), flush=True)
         want = pool.map(oracle_job, jobs, chunksize=2)
         bufs = [corpus.make_buffer(j[0], j[1], j[2]) for j in jobs]
         if sections:
