@@ -134,6 +134,8 @@ static void build_chains(EmuChains &c, const uint8_t *src, uint32_t n)
  * levels 4-9, a match-finding strategy; switched with emu_set_table */
 static uint32_t g_stair_min = 0; /* (the emulation searches every chain as a staircase unless told otherwise) */
 extern "C" void emu_set_stair_min(uint32_t v) { g_stair_min = v; }
+int g_sg_one = 1; /* lz_parse_seg.h: chains below the budget searched by all lanes at once (SG_EVAL_ONE) */
+extern "C" void emu_set_one(int on) { g_sg_one = on; }
 static int g_use_table = 1;
 static uint32_t g_mt_cap = MT_CAP;
 extern "C" void emu_set_table_cap(uint32_t cap) { g_mt_cap = cap; }

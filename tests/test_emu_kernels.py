@@ -174,31 +174,34 @@ def test_match_table_entries_against_the_reference_walk(emu, oracle):
 
 
 def test_segmented_parser_search_modes(emu, oracle):
-    """The segmented parser's three ways to a match give the reference's stream: hops over the match
+    """The segmented parser's ways to a match give the reference's stream: hops over the match
     table (on / off), the staircase search over the shortest chains (for every chain / for long ones
-    only, the product's default / never), the reference's own walk."""
+    only, the product's default / never), chains below the chain budget searched by all lanes at once
+    (the product's default) or walked like the others, the reference's own walk."""
     if emu.inflate_only or emu.group8:
         pytest.skip("the segmented parser is exercised at 64 and 16 lanes")
     try:
         emu.emu_set_seg_mode(2)
-        for table in (1, 0):
-            for stair_min in (0, 256, 0xffffffff):
-                emu.emu_set_table(table)
-                emu.emu_set_stair_min(stair_min)
-                for kind, n in (("text", 90000), ("bitmap", 70000), ("table", 40000), ("runs", 30000), ("zero", 70000),
-                                ("random", 20000), ("object", 38240), ("text", 65275)):
-                    data = corpus.make_buffer(kind, n, n + table)
-                    for level in (6, 9, 4) if n <= 40000 else (6,):
-                        if emu.group16:
-                            assert parse_equals_oracle(emu, oracle, data, level), (table, stair_min, kind, n, level)
-                            continue
-                        rc, got = emu_compress(emu, data, level, 1)
-                        orc, want, _ = oracle.compress(data, level)
-                        assert rc == orc == 0 and got == want, (table, stair_min, kind, n, level)
+        for table, stair_min, one in ((1, 0, 1), (1, 256, 1), (1, 0xffffffff, 1), (0, 0, 1), (0, 256, 1),
+                                      (0, 0xffffffff, 1), (0, 256, 0), (0, 0xffffffff, 0), (1, 256, 0)):
+            emu.emu_set_table(table)
+            emu.emu_set_stair_min(stair_min)
+            emu.emu_set_one(one)
+            for kind, n in (("text", 90000), ("bitmap", 70000), ("table", 40000), ("runs", 30000), ("zero", 70000),
+                            ("random", 20000), ("object", 38240), ("text", 65275)):
+                data = corpus.make_buffer(kind, n, n + table)
+                for level in (6, 9, 4) if n <= 40000 else (6,):
+                    if emu.group16:
+                        assert parse_equals_oracle(emu, oracle, data, level), (table, stair_min, one, kind, n, level)
+                        continue
+                    rc, got = emu_compress(emu, data, level, 1)
+                    orc, want, _ = oracle.compress(data, level)
+                    assert rc == orc == 0 and got == want, (table, stair_min, one, kind, n, level)
     finally:
         emu.emu_set_seg_mode(0)
         emu.emu_set_table(1)
         emu.emu_set_stair_min(0)
+        emu.emu_set_one(1)
 
 
 def test_greedy_parser_with_and_without_an_lds_window(emu, oracle):

@@ -86,7 +86,13 @@
 #define SG_STAIR_MIN 256u /* chains at least this long are searched as a staircase (LzJob.stair_min) */
 #endif
 #ifndef SG_ONE
-#define SG_ONE 1 /* 0: chains that fit one load are walked like the others */
+#define SG_ONE 1 /* 0: chains below the chain budget are walked like the others */
+#endif
+#ifdef ZSC_WAVE_EMU
+extern int g_sg_one; /* the host emulation can switch the lane-parallel search off (tests of the walk) */
+#define SG_ONE_ON g_sg_one
+#else
+#define SG_ONE_ON 1
 #endif
 #ifndef SG_STAIR
 #define SG_STAIR 1 /* 0: every search is the reference's walk along p's own chain (the parser as it was) */
@@ -952,7 +958,7 @@ DEV void sg_parse_segment(const LzJob &job, SgLds *lds, const SgScratch &scr, ui
                 int bail = 0, searched = 0;
                 /* (one comparison: the chain is shorter than the budget and than four loads, and there is room for a longer match) */
                 const uint32_t one_lim = best < look ? (budget < 4u * GRP + 1u ? budget : 4u * GRP + 1u) : 0u;
-                if (SG_ONE && job.cfg.hbits == 15u && total < one_lim) {
+                if (SG_ONE && SG_ONE_ON && job.cfg.hbits == 15u && total < one_lim) {
                     if (total > GRP) {
                         SG_LOAD(e1, 1u);
                         if (total > 2u * GRP) {
