@@ -269,8 +269,8 @@ DEV void sg_phase_begin(const LzJob &job, SgLds *lds, int w)
                 (LEN) = 256;                                                                  \
                 /* (rare: nothing of this is worked out ahead of the loops around it) */      \
                 uint32_t _rp = rp, _cap = cap;                                                \
-                OPAQUE_UNI(_rp);                                                              \
-                OPAQUE_UNI(_cap);                                                             \
+                GOPAQUE(_rp);                                                                 \
+                GOPAQUE(_cap);                                                                \
                 if (_cap > 256 && GUNI(lds->ring[_rq + 256]) == GUNI(lds->ring[_rp + 256])) { \
                     (LEN) = 257;                                                              \
                     if (_cap > 257 && GUNI(lds->ring[_rq + 257]) == GUNI(lds->ring[_rp + 257])) \

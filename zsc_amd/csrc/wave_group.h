@@ -29,6 +29,7 @@
 #undef GUNI
 #undef GSUM64
 #undef GMIN_U32
+#undef GOPAQUE
 
 #ifndef ZSC_GROUP
 #define ZSC_GROUP 64
@@ -46,6 +47,7 @@
 #define GUNI(x) UNI(x)
 #define GSUM64(in) WAVE_SUM(in)
 #define GMIN_U32(in) WAVE_MIN_U32(in)
+#define GOPAQUE(x) OPAQUE_UNI(x)
 #else
 #define GRP ZSC_GROUP
 #define GROUPS_PER_WAVE (64 / ZSC_GROUP)
@@ -58,6 +60,7 @@
 #define GUNI(x) (x)
 #define GSUM64(in) group_sum_u64(in)
 #define GMIN_U32(in) group_min_u32(in)
+#define GOPAQUE(x) asm volatile("" : "+v"(x)) /* (group-uniform values live in vector registers) */
 #ifndef ZSC_GROUP_SUM_DEFINED
 #define ZSC_GROUP_SUM_DEFINED
 DEV uint64_t group_sum_u64(uint64_t v)
