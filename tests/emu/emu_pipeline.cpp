@@ -275,8 +275,20 @@ extern "C" void emu_set_seg_mode(int m) { g_seg_mode = m; }
 
 static bool g_job_seg_ok = true; /* sections: may the segmented parser take the run with its joints? */
 
-static void run_parse_seg(const LzJob &job0, int order)
+/* as the runtime does when every buffer of a batch goes to the segmented parser: no k_link_prev, the
+ * parser gets the bucket directories and works hib / cnt out itself (lz_parse_seg.h: sg_link) */
+static int g_link_in_parser = 1;
+static const uint16_t *g_dir = nullptr;
+extern "C" void emu_set_link_in_parser(int on) { g_link_in_parser = on; }
+
+static void run_parse_seg(const LzJob &job00, int order)
 {
+    LzJob job0 = job00;
+    if (g_link_in_parser && g_dir) {
+        job0.dir = g_dir;
+        job0.hib = nullptr; /* (must not be read) */
+        job0.cnt = nullptr;
+    }
     LzJob job = job0;
     SgLds *lds = (SgLds *)malloc(sizeof(SgLds));
     memset(lds, 0x6B, sizeof(SgLds));
@@ -405,6 +417,8 @@ extern "C" int emu_parse(const uint8_t *src, uint32_t n, int level, int strategy
     job.rank = c.rank.data();
     job.hib = c.hib.data();
     job.cnt = c.cnt.data();
+    job.dir = nullptr;
+    g_dir = c.dir.data();
     job.r2 = c.r2.empty() ? nullptr : c.r2.data();
     job.stair_min = g_stair_min;
     job.syms = syms;
@@ -459,6 +473,8 @@ extern "C" int emu_compress(const uint8_t *src, uint32_t n, int level, int wrap,
     job.rank = c.rank.data();
     job.hib = c.hib.data();
     job.cnt = c.cnt.data();
+    job.dir = nullptr;
+    g_dir = c.dir.data();
     job.r2 = c.r2.empty() ? nullptr : c.r2.data();
     job.stair_min = g_stair_min;
     job.syms = syms.data();
@@ -555,6 +571,8 @@ struct EmuSecRunner {
             job.rank = c.rank.data();
             job.hib = c.hib.data();
             job.cnt = c.cnt.data();
+            job.dir = nullptr;
+            g_dir = c.dir.data();
             if (r.sched.empty())
                 build_table(c, level, strategy);
             job.r2 = c.r2.empty() ? nullptr : c.r2.data();

@@ -177,31 +177,35 @@ def test_segmented_parser_search_modes(emu, oracle):
     """The segmented parser's ways to a match give the reference's stream: hops over the match
     table (on / off), the staircase search over the shortest chains (for every chain / for long ones
     only, the product's default / never), chains below the chain budget searched by all lanes at once
-    (the product's default) or walked like the others, the reference's own walk."""
+    (the product's default) or walked like the others, the reference's own walk; chain lengths and the links
+    into the previous tile worked out by the parser from the bucket directories or read from k_link_prev's arrays."""
     if emu.inflate_only or emu.group8:
         pytest.skip("the segmented parser is exercised at 64 and 16 lanes")
     try:
         emu.emu_set_seg_mode(2)
-        for table, stair_min, one in ((1, 0, 1), (1, 256, 1), (1, 0xffffffff, 1), (0, 0, 1), (0, 256, 1),
-                                      (0, 0xffffffff, 1), (0, 256, 0), (0, 0xffffffff, 0), (1, 256, 0)):
+        for table, stair_min, one, link in ((1, 0, 1, 1), (1, 256, 1, 1), (1, 0xffffffff, 1, 1), (0, 0, 1, 1), (0, 256, 1, 1),
+                                            (0, 0xffffffff, 1, 1), (0, 256, 0, 1), (0, 0xffffffff, 0, 0), (1, 256, 0, 0),
+                                            (0, 256, 1, 0)):
             emu.emu_set_table(table)
             emu.emu_set_stair_min(stair_min)
             emu.emu_set_one(one)
+            emu.emu_set_link_in_parser(link)  # 0: chain lengths and links from k_link_prev's arrays
             for kind, n in (("text", 90000), ("bitmap", 70000), ("table", 40000), ("runs", 30000), ("zero", 70000),
                             ("random", 20000), ("object", 38240), ("text", 65275)):
                 data = corpus.make_buffer(kind, n, n + table)
                 for level in (6, 9, 4) if n <= 40000 else (6,):
                     if emu.group16:
-                        assert parse_equals_oracle(emu, oracle, data, level), (table, stair_min, one, kind, n, level)
+                        assert parse_equals_oracle(emu, oracle, data, level), (table, stair_min, one, link, kind, n, level)
                         continue
                     rc, got = emu_compress(emu, data, level, 1)
                     orc, want, _ = oracle.compress(data, level)
-                    assert rc == orc == 0 and got == want, (table, stair_min, one, kind, n, level)
+                    assert rc == orc == 0 and got == want, (table, stair_min, one, link, kind, n, level)
     finally:
         emu.emu_set_seg_mode(0)
         emu.emu_set_table(1)
         emu.emu_set_stair_min(0)
         emu.emu_set_one(1)
+        emu.emu_set_link_in_parser(1)
 
 
 def test_greedy_parser_with_and_without_an_lds_window(emu, oracle):

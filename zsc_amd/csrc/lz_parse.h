@@ -106,6 +106,8 @@ typedef struct {
     const uint16_t *rank;   /* this buffer: index of a position in its tile's sorted array */
     const uint16_t *hib;    /* this buffer: last index of the position's bucket in the previous tile */
     const uint32_t *cnt;    /* this buffer: chain lengths in the own | previous tile (hash_sort.h) */
+    const uint16_t *dir;    /* segmented parser: the bucket directories of this buffer's tiles (ZD_DIR_STRIDE apart); then
+                               hib / cnt are not read -- the parser works them out itself (sg_link), k_link_prev need not run */
     uint32_t stair_min;     /* segmented parser: chains at least this long are searched as a staircase (lz_parse_seg.h) */
     const uint32_t *r2;     /* this buffer: the match table, longest_match(p, 2) per position (match_table.h), or null */
     uint32_t *syms;         /* this buffer's symbol slots */

@@ -165,6 +165,28 @@ DEV uint32_t sg_base(const ZdLevel &cfg, uint32_t p, uint32_t n)
     return sg_base_at(cfg, p, n, ZD_MIN_LOOKAHEAD);
 }
 
+/* What k_link_prev (hash_sort.h: hs_link_prev) would have written for position x, whose rank is rk:
+ * rank | hib << 16 and cnt, from the bucket directories of x's tile and of the one before it.  The
+ * parser asks for 64 consecutive positions at a time, so this is two gathers per 48 positions in
+ * place of a kernel that does the same gathers for every position and writes the answers out. */
+template <class L>
+DEV void sg_link(const LzJob &job, const L *lds, const LzState &st, uint32_t x, uint32_t rk, uint32_t &rh,
+                 uint32_t &cn)
+{
+    const uint32_t w = lds_u32(lds->ring, lz_ridx<L>(st, x));
+    const uint32_t h = (((w & 0xffu) << 10) ^ (((w >> 8) & 0xffu) << 5) ^ ((w >> 16) & 0xffu)) & ZD_HASH_MASK;
+    const uint32_t t = x >> 15;
+    const uint16_t *d = job.dir + (uint64_t)t * ZD_DIR_STRIDE;
+    uint32_t c = rk - (uint32_t)d[h], hb = 0xffffu;
+    if (t != 0u) {
+        const uint32_t two = ld_u32((const uint8_t *)(d - ZD_DIR_STRIDE + h)); /* dir_prev[h], dir_prev[h + 1] */
+        hb = ((two >> 16) - 1u) & 0xffffu; /* 0xffff: bucket empty from the start */
+        c |= ((two >> 16) - (two & 0xffffu)) << 16;
+    }
+    rh = rk | (hb << 16);
+    cn = c;
+}
+
 /* number of segments of the super-step that starts at S0 */
 DEV uint32_t sg_nact(uint32_t S0, uint32_t n)
 {
@@ -913,8 +935,16 @@ DEV void sg_parse_segment(const LzJob &job, SgLds *lds, const SgScratch &scr, ui
                 {
                     const uint32_t x = p + (uint32_t)GLANE;
                     const int ok = x + 2 < job.n;
-                    LV(mrk) = ok ? ((uint32_t)job.rank[x] | ((uint32_t)job.hib[x] << 16)) : 0u;
-                    LV(mcn) = ok ? job.cnt[x] : 0u;
+                    if (job.dir) {
+                        uint32_t rh_x = 0, cn_x = 0;
+                        if (ok)
+                            sg_link<L>(job, lds, st, x, (uint32_t)job.rank[x], rh_x, cn_x);
+                        LV(mrk) = rh_x;
+                        LV(mcn) = cn_x;
+                    } else {
+                        LV(mrk) = ok ? ((uint32_t)job.rank[x] | ((uint32_t)job.hib[x] << 16)) : 0u;
+                        LV(mcn) = ok ? job.cnt[x] : 0u;
+                    }
                 }
             }
             const uint32_t rh = GREADLANE(mrk, p - mt_at), cn = GREADLANE(mcn, p - mt_at);
@@ -1059,13 +1089,21 @@ DEV void sg_parse_segment(const LzJob &job, SgLds *lds, const SgScratch &scr, ui
                             if (tmin > SG_FAR_OVER && l1 >= GRP) {
                                 for (uint32_t o = best - 3u; o <= best - 2u; o++) {
                                     if (p + o - mt_at >= GRP && (uint64_t)p + o + 3u <= job.n) {
-                                        const uint32_t c = GUNI(job.cnt[p + o]);
+                                        uint32_t c, rhx;
+                                        if (job.dir) {
+                                            sg_link<L>(job, lds, st, p + o, (uint32_t)job.rank[p + o], rhx, c);
+                                            c = GUNI(c);
+                                            rhx = GUNI(rhx);
+                                        } else {
+                                            c = GUNI(job.cnt[p + o]);
+                                            rhx = GUNI((uint32_t)job.rank[p + o]) | (GUNI((uint32_t)job.hib[p + o]) << 16);
+                                        }
                                         const uint32_t t = (c & 0xffffu) + (c >> 16);
                                         if (t < tmin) {
                                             tmin = t;
                                             j = o;
                                             cnj = c;
-                                            rhj = GUNI((uint32_t)job.rank[p + o]) | (GUNI((uint32_t)job.hib[p + o]) << 16);
+                                            rhj = rhx;
                                         }
                                     }
                                 }

@@ -279,6 +279,7 @@ __global__ __launch_bounds__(64) void k_parse(const uint8_t *__restrict__ in,
     job.rank = rank + buf.rank_off;
     job.hib = hib + buf.rank_off;
     job.cnt = nullptr;
+    job.dir = nullptr;
     job.r2 = nullptr;
     job.stair_min = 0xffffffffu;
     job.syms = syms + buf.sym_off;
@@ -305,6 +306,7 @@ __global__ __launch_bounds__(SG_W * 64, SG_MIN_WAVES) void k_parse_seg(const uin
                                                          const uint16_t *__restrict__ rank,
                                                          const uint16_t *__restrict__ hib,
                                                          const uint32_t *__restrict__ cnt,
+                                                         const uint16_t *__restrict__ dir,
                                                          const uint32_t *__restrict__ r2,
                                                          uint32_t *__restrict__ syms,
                                                          ZdBlockRec *__restrict__ recs,
@@ -327,6 +329,8 @@ __global__ __launch_bounds__(SG_W * 64, SG_MIN_WAVES) void k_parse_seg(const uin
     job.rank = rank + buf.rank_off;
     job.hib = hib + buf.rank_off;
     job.cnt = cnt + buf.rank_off;
+    /* given the directories, the parser works hib / cnt out itself and k_link_prev has not run (sg_link) */
+    job.dir = dir ? dir + (uint64_t)buf.tile0 * ZD_DIR_STRIDE : nullptr;
     /* the match table covers plain buffers (match_table.h); a run with joints is searched as before */
     job.r2 = r2 && buf.sched_n == 0 ? r2 + buf.rank_off : nullptr;
     job.stair_min = stair_min;
@@ -433,6 +437,7 @@ __global__ __launch_bounds__(64) void k_parse_simple(const uint8_t *__restrict__
     job.rank = nullptr;
     job.hib = nullptr;
     job.cnt = nullptr;
+    job.dir = nullptr;
     job.r2 = nullptr;
     job.stair_min = 0xffffffffu;
     job.syms = syms + buf.sym_off;
@@ -479,6 +484,7 @@ __global__ __launch_bounds__(64) void k_parse_fast(const uint8_t *__restrict__ i
     job.rank = rank + buf.rank_off;
     job.hib = hib + buf.rank_off;
     job.cnt = nullptr;
+    job.dir = nullptr;
     job.r2 = nullptr;
     job.stair_min = 0xffffffffu;
     job.syms = syms + buf.sym_off;
@@ -1251,13 +1257,18 @@ extern "C" ZlibReturn zsc_hip_deflate_plan_run(zsc_hip_deflate_plan *pl, const v
         mark();
         /* Z_HUFFMAN_ONLY / Z_RLE look at no earlier data than the previous byte: no chains */
         const bool simple = pl->strategy == (uint32_t)Z_HUFFMAN_ONLY || pl->strategy == (uint32_t)Z_RLE;
+        const bool link_in_parser = !simple && cfg.slow && sb.cseg == sb.count && !pl->use_table &&
+                                    getenv("ZSC_HIP_LINK_KERNEL") == nullptr; /* (the variable: A/B and debugging) */
         if (!simple) {
             hipLaunchKernelGGL(k_hash_sort, dim3(sb.ntiles), dim3(HS_WAVES * 64), 0, st, in, bufs,
                                (const uint32_t *)sb.d_tile_owner.p, sorted, tmp_syms, rank, dir,
                                sb.ntiles);
-            hipLaunchKernelGGL(k_link_prev, dim3(sb.ntiles), dim3(HS_WAVES * 64), 0, st, in, bufs,
-                               (const uint32_t *)sb.d_tile_owner.p, (const uint16_t *)dir,
-                               (const uint16_t *)rank, hib, cnt, sb.ntiles);
+            /* chain lengths and the links into the previous tile, for every position -- unless every buffer of
+             * the batch goes to the segmented parser, which works them out for the positions it visits */
+            if (!link_in_parser)
+                hipLaunchKernelGGL(k_link_prev, dim3(sb.ntiles), dim3(HS_WAVES * 64), 0, st, in, bufs,
+                                   (const uint32_t *)sb.d_tile_owner.p, (const uint16_t *)dir,
+                                   (const uint16_t *)rank, hib, cnt, sb.ntiles);
         }
         mark();
         if (!simple) {
@@ -1288,8 +1299,8 @@ extern "C" ZlibReturn zsc_hip_deflate_plan_run(zsc_hip_deflate_plan *pl, const v
                 hipLaunchKernelGGL(kern, dim3(sb.cseg), dim3(SG_W * 64), 0, st, in, bufs,
                                    (const uint32_t *)sb.d_order.p, (const uint32_t *)sorted,
                                    (const uint16_t *)rank, (const uint16_t *)hib,
-                                   (const uint32_t *)cnt,
-                                   pl->use_table ? (const uint32_t *)pl->d_r2.p : nullptr,                                    tmp_syms, recs,
+                                   (const uint32_t *)cnt, link_in_parser ? (const uint16_t *)dir : nullptr,
+                                   pl->use_table ? (const uint32_t *)pl->d_r2.p : nullptr, tmp_syms, recs,
                                    pout, (uint32_t *)pl->d_seg_tok.p,
                                    (const ZdSched *)pl->d_sched.p, cfg, pl->stair_min, 0u, sb.cseg);
             }
