@@ -172,16 +172,21 @@ static inline uint32_t emu_brev32(uint32_t v)
 #define READLANE(name, l) \
     ((decltype(name))__builtin_amdgcn_readlane((int)(name), __builtin_amdgcn_readfirstlane((int)(l))))
 
+/* Exclusive prefix sum over the 64 lanes on the DPP path of the vector ALU (no trips through LDS):
+ * within each row of 16 by shifts of 1, 2, 4, 8 (a lane without a source in its row adds 0), then
+ * lane 15 of a row onto the next row, and lane 31 onto the upper half. */
+#define WAVE_DPP_ADD_STEP(x, ctrl, rows) \
+    ((x) += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)(x), (ctrl), (rows), 0xf, true))
 DEV uint32_t wave_exscan_u32(uint32_t v, uint32_t &total)
 {
     uint32_t x = v;
-#pragma unroll
-    for (int d = 1; d < 64; d <<= 1) {
-        uint32_t y = __shfl_up(x, d);
-        if ((int)(threadIdx.x & 63) >= d)
-            x += y;
-    }
-    total = __shfl(x, 63);
+    WAVE_DPP_ADD_STEP(x, 0x111, 0xf); /* row_shr:1 */
+    WAVE_DPP_ADD_STEP(x, 0x112, 0xf); /* row_shr:2 */
+    WAVE_DPP_ADD_STEP(x, 0x114, 0xf); /* row_shr:4 */
+    WAVE_DPP_ADD_STEP(x, 0x118, 0xf); /* row_shr:8 */
+    WAVE_DPP_ADD_STEP(x, 0x142, 0xa); /* row_bcast:15 onto rows 1 and 3 */
+    WAVE_DPP_ADD_STEP(x, 0x143, 0xc); /* row_bcast:31 onto rows 2 and 3 */
+    total = (uint32_t)__builtin_amdgcn_readlane((int)x, 63);
     return x - v;
 }
 #define WAVE_EXSCAN(in, out, total) ((out) = wave_exscan_u32((in), (total)))
