@@ -1431,6 +1431,11 @@ DEV void sg_append(const LzJob &job, SgOut *o, const uint32_t *tok, uint32_t fro
     uint32_t nsyms = UNI(o->nsyms), nblocks = UNI(o->nblocks);
     uint32_t blk_sym0 = UNI(o->blk_sym0), blk_in0 = UNI(o->blk_in0), cov = UNI(o->cov);
     uint32_t i = from;
+    /* the next batch's tokens are asked for while this one is worked on: the resolver is one wave, the
+     * others wait for it, and every batch would otherwise begin with a trip to memory */
+    LANEVAR(uint32_t, pf);
+    uint32_t pf_at = 0xffffffffu;
+    FOR_LANES { LV(pf) = 0; }
     while (i < to) {
         /* never let a batch run across a block boundary */
         uint32_t room = may_cut ? job.cfg.sym_cap - (nsyms - blk_sym0) : WAVE;
@@ -1440,10 +1445,18 @@ DEV void sg_append(const LzJob &job, SgOut *o, const uint32_t *tok, uint32_t fro
         LANEVAR(uint32_t, tlen);
         LANEVAR(uint32_t, tex);
         LANEVAR(uint32_t, tk);
+        if (pf_at == i) {
+            FOR_LANES { LV(tk) = (uint32_t)LANE < cnt ? LV(pf) : 0u; }
+        } else {
+            FOR_LANES { LV(tk) = (uint32_t)LANE < cnt ? tok[i + (uint32_t)LANE] : 0u; }
+        }
+        if (i + cnt < to) {
+            pf_at = i + cnt;
+            FOR_LANES { LV(pf) = pf_at + (uint32_t)LANE < to ? tok[pf_at + (uint32_t)LANE] : 0u; }
+        }
         FOR_LANES
         {
-            uint32_t t = (uint32_t)LANE < cnt ? tok[i + (uint32_t)LANE] : 0u;
-            LV(tk) = t;
+            const uint32_t t = LV(tk);
             LV(tlen) = (uint32_t)LANE < cnt ? ((t >> 16) ? (t & 0xffu) + 3u : 1u) : 0u;
         }
         uint32_t total;
