@@ -748,6 +748,39 @@ DEV void sg_phase_begin(const LzJob &job, SgLds *lds, int w)
         LV(hr2) = (uint64_t)x + 4u <= job.n ? job.r2[x] : MT_INCOMPLETE;                      \
     }
 
+/* What a parser records of the positions of its own segment that it visits with no match pending
+ * lives in one register, a lane per position of the current block of GRP: the token count there,
+ * bit 16 "visited fresh", bit 17 "a literal was owed".  When the parse leaves the block the counts go
+ * to sidx, and two ballots make the block's words of the trace bitmaps -- kinds first: whoever sees a
+ * bit of a trace word finds its kind in place. */
+#define SG_TRACE_FLUSH()                                                                      \
+    do {                                                                                      \
+        LANEVAR(int, _fr);                                                                    \
+        LANEVAR(int, _kd);                                                                    \
+        FOR_GLANES                                                                             \
+        {                                                                                     \
+            sidx[sd_blk * GRP + (uint32_t)GLANE] = (uint16_t)LV(sdx);                          \
+            LV(_fr) = (int)((LV(sdx) >> 16) & 1u);                                            \
+            LV(_kd) = (int)((LV(sdx) >> 17) & 1u);                                            \
+        }                                                                                     \
+        const uint64_t _mf = GBALLOT(_fr), _mk = GBALLOT(_kd);                                  \
+        ON_GLANE0                                                                              \
+        {                                                                                     \
+            if (GRP >= 32u) {                                                                 \
+                for (uint32_t _j = 0; _j < GRP / 32u; _j++) {                                 \
+                    const uint32_t _w = sd_blk * (GRP / 32u) + _j;                            \
+                    lds->tkind[s][_w] = (uint32_t)(_mk >> (32u * _j));                        \
+                    LDS_STORE_REL(&lds->trace[s][_w], (uint32_t)(_mf >> (32u * _j)));         \
+                }                                                                             \
+            } else { /* (narrow groups: part of a word; this parser is the word's only writer) */ \
+                const uint32_t _w = sd_blk * GRP / 32u, _sh = sd_blk * GRP % 32u;             \
+                const uint32_t _m = ((1u << (GRP & 31u)) - 1u) << _sh;                        \
+                lds->tkind[s][_w] = (lds->tkind[s][_w] & ~_m) | ((uint32_t)_mk << _sh);       \
+                LDS_STORE_REL(&lds->trace[s][_w], (lds->trace[s][_w] & ~_m) | ((uint32_t)_mf << _sh)); \
+            }                                                                                 \
+        }                                                                                     \
+    } while (0)
+
 /* one token to the segment's token area (through a register, 64 at a time) */
 #define SG_EMIT(SYM)                                                                          \
     do {                                                                                      \
@@ -802,7 +835,7 @@ DEV void sg_parse_segment(const LzJob &job, SgLds *lds, const SgScratch &scr, ui
      *   mrk/mcn  rank|hib and cnt of 64 consecutive positions
      *   pw       256 bytes of the window around p
      *   pv       the string at p as the long compare wants it (dword l = bytes 4l..4l+3)
-     *   stg      tokens not yet written out;  sdx  token counts at fresh positions */
+     *   stg      tokens not yet written out;  sdx  token counts and kinds at fresh positions (SG_TRACE_FLUSH) */
     LANEVAR(uint32_t, mrk);
     LANEVAR(uint32_t, mcn);
     LANEVAR(uint32_t, pv);
@@ -818,8 +851,7 @@ DEV void sg_parse_segment(const LzJob &job, SgLds *lds, const SgScratch &scr, ui
     uint32_t lit = 0;                      /* the byte at p-1 */
     if (pending)
         lit = GUNI(lds->ring[lz_ridx<L>(st, p - 1u)]);
-    uint32_t tw = 0, tk = 0, tw_idx = 0xffffffffu; /* trace word (and its kind bits) being filled */
-    uint32_t sd_blk = 0xffffffffu;         /* 64-position block sdx belongs to */
+    uint32_t sd_blk = 0xffffffffu;         /* block of GRP positions sdx belongs to */
 
     for (;;) {
         uint32_t look = st.data_end - p;
@@ -856,30 +888,17 @@ DEV void sg_parse_segment(const LzJob &job, SgLds *lds, const SgScratch &scr, ui
             }
         } else if (fresh) { /* p >= a_s always: every parser starts inside its segment */
             const uint32_t r = p - a_s;
-            if ((r >> 5) != tw_idx) {
-                if (tw_idx != 0xffffffffu) {
-                    ON_GLANE0
-                    {
-                        /* kinds first: whoever sees a bit of the trace word finds its kind in place */
-                        lds->tkind[s][tw_idx] = tk;
-                        LDS_STORE_REL(&lds->trace[s][tw_idx], tw);
-                    }
-                }
-                tw_idx = r >> 5;
-                tw = tk = 0;
-            }
-            tw |= 1u << (r & 31u);
-            tk |= (uint32_t)pending << (r & 31u);
             if (r / GRP != sd_blk) {
-                if (sd_blk != 0xffffffffu) {
-                    FOR_GLANES { sidx[sd_blk * GRP + (uint32_t)GLANE] = (uint16_t)LV(sdx); }
-                }
+                if (sd_blk != 0xffffffffu)
+                    SG_TRACE_FLUSH();
                 sd_blk = r / GRP;
+                FOR_GLANES { LV(sdx) = 0; }
             }
+            const uint32_t rec = ntok | 0x10000u | ((uint32_t)pending << 17);
             FOR_GLANES
             {
                 if ((uint32_t)GLANE == r % GRP)
-                    LV(sdx) = ntok;
+                    LV(sdx) = rec;
             }
         }
 
@@ -1353,15 +1372,10 @@ DEV void sg_parse_segment(const LzJob &job, SgLds *lds, const SgScratch &scr, ui
         if ((uint32_t)GLANE < nstaged)
             tok[ntok - nstaged + (uint32_t)GLANE] = LV(stg);
     }
-    if (sd_blk != 0xffffffffu) {
-        FOR_GLANES { sidx[sd_blk * GRP + (uint32_t)GLANE] = (uint16_t)LV(sdx); }
-    }
+    if (sd_blk != 0xffffffffu)
+        SG_TRACE_FLUSH();
     ON_GLANE0
     {
-        if (tw_idx != 0xffffffffu) {
-            lds->tkind[s][tw_idx] = tk;
-            LDS_STORE_REL(&lds->trace[s][tw_idx], tw);
-        }
         SgWave *me = &lds->wv[s];
         me->exit_kind = exit_kind;
         me->exit_p = p;
