@@ -255,7 +255,7 @@ DEV void sg_phase_begin(const LzJob &job, SgLds *lds, int w)
         const uint32_t _v = (B)*GRP + (uint32_t)GLANE;                                         \
         int32_t _i = _v < nA ? hiA - (int32_t)_v : hiB - (int32_t)(_v - nA) - (int32_t)ZD_TILE; \
         _i = _v < total ? _i : 0;                                                             \
-        LV(E) = runA[_i];                                                                     \
+        LV(E) = job.sorted[(uint32_t)((int32_t)tileA + _i)]; /* (the tile's run starts at sorted + tileA) */ \
     }
 
 /* the string at p, four bytes a lane (dword l = bytes 4l .. 4l+3) */
@@ -987,7 +987,6 @@ DEV void sg_parse_segment(const LzJob &job, SgLds *lds, const SgScratch &scr, ui
                 SG_COUNT(5, 1);
                 const int32_t hiA = (int32_t)(rh & 0xffffu) - 1, hiB = (int32_t)(rh >> 16);
                 const uint32_t tileA = p & ~ZD_TILE_MASK;
-                const uint32_t *runA = job.sorted + (uint64_t)(p >> 15) * ZD_TILE;
                 const uint32_t far = p - st.base > job.cfg.max_dist;
                 uint32_t floor_pos = far ? p - job.cfg.max_dist : st.base;
                 const uint32_t cap = look < 258u ? look : 258u;
@@ -1135,7 +1134,6 @@ DEV void sg_parse_segment(const LzJob &job, SgLds *lds, const SgScratch &scr, ui
                         const uint32_t nAj = cnj & 0xffffu, totj = nAj + (cnj >> 16);
                         const int32_t hiAj = (int32_t)(rhj & 0xffffu) - 1, hiBj = (int32_t)(rhj >> 16);
                         const uint32_t tileJ = (p + j) & ~ZD_TILE_MASK;
-                        const uint32_t *runJ = job.sorted + (uint64_t)((p + j) >> 15) * ZD_TILE;
                         /* A candidate longer than best matches ALL of p's bytes 0 .. best: the four that end
                          * at best (the reference's pre-check looks at the last two of them), the first four,
                          * and four in the middle are looked at before the long compare is spent on it.
@@ -1165,7 +1163,7 @@ DEV void sg_parse_segment(const LzJob &job, SgLds *lds, const SgScratch &scr, ui
                                     const uint32_t _v = bb * GRP + (uint32_t)GLANE;
                                     int32_t _i = _v < nAj ? hiAj - (int32_t)_v : hiBj - (int32_t)(_v - nAj) - (int32_t)ZD_TILE;
                                     _i = _v < totj ? _i : 0;
-                                    LV(ej) = runJ[_i];
+                                    LV(ej) = job.sorted[(uint32_t)((int32_t)tileJ + _i)];
                                 }
                             }
                             SG_COUNT(0, 1);
