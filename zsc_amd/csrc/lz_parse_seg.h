@@ -836,15 +836,17 @@ DEV void sg_parse_segment(const LzJob &job, SgLds *lds, const SgScratch &scr, ui
      *   pw       256 bytes of the window around p
      *   pv       the string at p as the long compare wants it (dword l = bytes 4l..4l+3)
      *   stg      tokens not yet written out;  sdx  token counts and kinds at fresh positions (SG_TRACE_FLUSH) */
-    LANEVAR(uint32_t, mrk);
-    LANEVAR(uint32_t, mcn);
+    LANEVAR(uint32_t, mha); /* of 64 consecutive positions: rank - 1 (the newest older entry of the own tile's run), */
+    LANEVAR(uint32_t, mhb); /* ... hib, */
+    LANEVAR(uint32_t, mna); /* ... the number of older entries in the own tile */
+    LANEVAR(uint32_t, mto); /* ... and in both tiles: four v_readlane and no unpacking per search */
     LANEVAR(uint32_t, pv);
     LANEVAR(uint32_t, stg);
     LANEVAR(uint32_t, sdx);
     LANEVAR(uint32_t, hop); /* hops of the positions from hop_at on, and the input bytes there */
     LANEVAR(uint32_t, hby);
     LANEVAR(uint32_t, hr2); /* ... and their table entries themselves */
-    FOR_GLANES { LV(mrk) = LV(mcn) = LV(pv) = LV(stg) = LV(sdx) = LV(hop) = LV(hby) = LV(hr2) = 0; }
+    FOR_GLANES { LV(mha) = LV(mhb) = LV(mna) = LV(mto) = LV(pv) = LV(stg) = LV(sdx) = LV(hop) = LV(hby) = LV(hr2) = 0; }
     uint32_t hop_at = p + 4096u; /* (out of range, as the other caches) */
     /* the two caches start out of range of p, so that their one range test fails */
     uint32_t mt_at = p + 4096u, pv_at = 0xffffffffu;
@@ -954,20 +956,21 @@ DEV void sg_parse_segment(const LzJob &job, SgLds *lds, const SgScratch &scr, ui
                 {
                     const uint32_t x = p + (uint32_t)GLANE;
                     const int ok = x + 2 < job.n;
+                    uint32_t rh_x = 0, cn_x = 0;
                     if (job.dir) {
-                        uint32_t rh_x = 0, cn_x = 0;
                         if (ok)
                             sg_link<L>(job, lds, st, x, (uint32_t)job.rank[x], rh_x, cn_x);
-                        LV(mrk) = rh_x;
-                        LV(mcn) = cn_x;
                     } else {
-                        LV(mrk) = ok ? ((uint32_t)job.rank[x] | ((uint32_t)job.hib[x] << 16)) : 0u;
-                        LV(mcn) = ok ? job.cnt[x] : 0u;
+                        rh_x = ok ? ((uint32_t)job.rank[x] | ((uint32_t)job.hib[x] << 16)) : 0u;
+                        cn_x = ok ? job.cnt[x] : 0u;
                     }
+                    LV(mha) = (rh_x & 0xffffu) - 1u;
+                    LV(mhb) = rh_x >> 16;
+                    LV(mna) = cn_x & 0xffffu;
+                    LV(mto) = (cn_x & 0xffffu) + (cn_x >> 16);
                 }
             }
-            const uint32_t rh = GREADLANE(mrk, p - mt_at), cn = GREADLANE(mcn, p - mt_at);
-            const uint32_t nA = cn & 0xffffu, total = nA + (cn >> 16);
+            const uint32_t nA = GREADLANE(mna, p - mt_at), total = GREADLANE(mto, p - mt_at);
             /* A match pending: anything longer shares prev_len + 1 bytes with p, so every trigram in
              * them has been seen before -- if one of them (of those whose chain lengths are in the
              * register cache) has an EMPTY chain, there is nothing longer and no need to look. */
@@ -978,14 +981,14 @@ DEV void sg_parse_segment(const LzJob &job, SgLds *lds, const SgScratch &scr, ui
                 FOR_GLANES
                 {
                     const uint32_t l = (uint32_t)GLANE;
-                    LV(empty) = l > l0 && l <= l0 + (prev_len - 2u) && LV(mcn) == 0u && (uint64_t)mt_at + l + 3u <= job.n;
+                    LV(empty) = l > l0 && l <= l0 + (prev_len - 2u) && LV(mto) == 0u && (uint64_t)mt_at + l + 3u <= job.n;
                 }
                 none_longer = GBALLOT(empty) != 0;
                 SG_COUNT(9, (unsigned)none_longer);
             }
             if (total != 0 && !none_longer) {
                 SG_COUNT(5, 1);
-                const int32_t hiA = (int32_t)(rh & 0xffffu) - 1, hiB = (int32_t)(rh >> 16);
+                const int32_t hiA = (int32_t)GREADLANE(mha, p - mt_at), hiB = (int32_t)GREADLANE(mhb, p - mt_at);
                 const uint32_t tileA = p & ~ZD_TILE_MASK;
                 const uint32_t far = p - st.base > job.cfg.max_dist;
                 uint32_t floor_pos = far ? p - job.cfg.max_dist : st.base;
@@ -1084,7 +1087,8 @@ DEV void sg_parse_segment(const LzJob &job, SgLds *lds, const SgScratch &scr, ui
                     int more = 1;
                     while (more) {
                         more = 0;
-                        uint32_t j = 0, cnj = 0, rhj = 0;
+                        uint32_t j = 0, nAj = 0, totj = 0;
+                        int32_t hiAj = 0, hiBj = 0;
                         if (best >= 3u) {
                             /* the shortest chain among those whose lengths are in the register cache */
                             LANEVAR(uint32_t, tkey);
@@ -1092,10 +1096,8 @@ DEV void sg_parse_segment(const LzJob &job, SgLds *lds, const SgScratch &scr, ui
                             const uint32_t l0 = p - mt_at, l1 = l0 + (best - 2u);
                             FOR_GLANES
                             {
-                                const uint32_t l = (uint32_t)GLANE, c = LV(mcn);
-                                LV(tkey) = (l >= l0 && l <= l1 && (uint64_t)mt_at + l + 3u <= job.n)
-                                               ? (c & 0xffffu) + (c >> 16)
-                                               : 0xffffffffu;
+                                const uint32_t l = (uint32_t)GLANE;
+                                LV(tkey) = (l >= l0 && l <= l1 && (uint64_t)mt_at + l + 3u <= job.n) ? LV(mto) : 0xffffffffu;
                             }
                             uint32_t tmin = GMIN_U32(tkey);
                             FOR_GLANES { LV(ismin) = LV(tkey) == tmin; }
@@ -1120,19 +1122,21 @@ DEV void sg_parse_segment(const LzJob &job, SgLds *lds, const SgScratch &scr, ui
                                         if (t < tmin) {
                                             tmin = t;
                                             j = o;
-                                            cnj = c;
-                                            rhj = rhx;
+                                            nAj = c & 0xffffu;
+                                            totj = t;
+                                            hiAj = (int32_t)(rhx & 0xffffu) - 1;
+                                            hiBj = (int32_t)(rhx >> 16);
                                         }
                                     }
                                 }
                             }
                         }
                         if (p + j - mt_at < GRP) {
-                            cnj = GREADLANE(mcn, p + j - mt_at);
-                            rhj = GREADLANE(mrk, p + j - mt_at);
+                            nAj = GREADLANE(mna, p + j - mt_at);
+                            totj = GREADLANE(mto, p + j - mt_at);
+                            hiAj = (int32_t)GREADLANE(mha, p + j - mt_at);
+                            hiBj = (int32_t)GREADLANE(mhb, p + j - mt_at);
                         }
-                        const uint32_t nAj = cnj & 0xffffu, totj = nAj + (cnj >> 16);
-                        const int32_t hiAj = (int32_t)(rhj & 0xffffu) - 1, hiBj = (int32_t)(rhj >> 16);
                         const uint32_t tileJ = (p + j) & ~ZD_TILE_MASK;
                         /* A candidate longer than best matches ALL of p's bytes 0 .. best: the four that end
                          * at best (the reference's pre-check looks at the last two of them), the first four,
@@ -1259,7 +1263,7 @@ DEV void sg_parse_segment(const LzJob &job, SgLds *lds, const SgScratch &scr, ui
                          * chain has entries between the first step to a level >= 5 and the last step */
                         uint32_t between = 0;
                         if (qs != 0xffffffffu && qs != where) {
-                            const uint32_t rk = rh & 0xffffu, hb = rh >> 16;
+                            const uint32_t rk = (uint32_t)hiA + 1u, hb = (uint32_t)hiB;
                             const uint32_t r1 = GUNI((uint32_t)job.rank[where]);
                             const uint32_t newer = (where >> 15) == (p >> 15) ? rk - 1u - r1 : nA + (hb - r1);
                             if (qs == p) {
