@@ -502,7 +502,7 @@ DEV void sg_phase_begin(const LzJob &job, SgLds *lds, int w)
         {                                                                                     \
             const uint32_t _v = (B)*GRP + (uint32_t)GLANE;                                     \
             const uint32_t q = tileA + (LV(E) & ZD_TILE_MASK) - (_v < nA ? 0u : ZD_TILE);     \
-            const int live = _v == 0 || (_v < total && q > floor_pos); /* :1519 */            \
+            const int live = _v < total && q > (_v == 0u ? hfloor : floor_pos);               \
             const uint32_t r = live ? lz_ridx<L>(st, q) : 0u;                                 \
             const uint32_t x = lds_u32(lds->ring, r) ^ s0123;                                 \
             const int m3 = live && (x & 0xffffffu) == 0u;                                     \
@@ -1017,25 +1017,25 @@ DEV void sg_parse_segment(const LzJob &job, SgLds *lds, const SgScratch &scr, ui
                             SG_LOAD(e3, 3u);
                         }
                     }
-                    const uint32_t ent0 = GREADLANE(e0, 0);
-                    const uint32_t q0 = tileA + (ent0 & ZD_TILE_MASK) - (nA ? 0u : ZD_TILE);
-                    /* the chain head may lie at exactly MAX_DIST (:2032), later links may not:
-                     * q0 > base and p - q0 <= MAX_DIST, as one comparison */
-                    if (q0 > floor_pos - far) {
-                        SG_EVAL_ONE(e0, 0u);
-                        if (!bail && best < nice && total > GRP) {
-                            SG_EVAL_ONE(e1, 1u);
-                            if (!bail && best < nice && total > 2u * GRP) {
-                                SG_EVAL_ONE(e2, 2u);
-                                if (!bail && best < nice && total > 3u * GRP)
-                                    SG_EVAL_ONE(e3, 3u);
-                            }
+                    /* The chain head may lie at exactly MAX_DIST (:2032), later links may not (:1519): q0 > base
+                     * and p - q0 <= MAX_DIST is q0 > floor_pos - far, and lane 0 tests its candidate against that.
+                     * A head that fails it has nothing but older entries behind it, which fail theirs: the search
+                     * finds nothing, which is what not calling longest_match comes to (match_length <= prev_length
+                     * either way). */
+                    const uint32_t hfloor = floor_pos - far;
+                    SG_EVAL_ONE(e0, 0u);
+                    if (!bail && best < nice && total > GRP) {
+                        SG_EVAL_ONE(e1, 1u);
+                        if (!bail && best < nice && total > 2u * GRP) {
+                            SG_EVAL_ONE(e2, 2u);
+                            if (!bail && best < nice && total > 3u * GRP)
+                                SG_EVAL_ONE(e3, 3u);
                         }
-                        head_seen = !bail;
-                        if (bail) {
-                            best = prev_len;
-                            where = cur_at;
-                        }
+                    }
+                    head_seen = !bail;
+                    if (bail) {
+                        best = prev_len;
+                        where = cur_at;
                     }
                     searched = !bail;
                 }
