@@ -840,13 +840,15 @@ DEV void sg_parse_segment(const LzJob &job, SgLds *lds, const SgScratch &scr, ui
     LANEVAR(uint32_t, mhb); /* ... hib, */
     LANEVAR(uint32_t, mna); /* ... the number of older entries in the own tile */
     LANEVAR(uint32_t, mto); /* ... and in both tiles: four v_readlane and no unpacking per search */
+    LANEVAR(uint32_t, mfl); /* ... the oldest position a link of its chain may have (:1519), minus one */
+    LANEVAR(uint32_t, mhf); /* ... and the same for the chain head, which may lie at exactly MAX_DIST (:2032) */
     LANEVAR(uint32_t, pv);
     LANEVAR(uint32_t, stg);
     LANEVAR(uint32_t, sdx);
     LANEVAR(uint32_t, hop); /* hops of the positions from hop_at on, and the input bytes there */
     LANEVAR(uint32_t, hby);
     LANEVAR(uint32_t, hr2); /* ... and their table entries themselves */
-    FOR_GLANES { LV(mha) = LV(mhb) = LV(mna) = LV(mto) = LV(pv) = LV(stg) = LV(sdx) = LV(hop) = LV(hby) = LV(hr2) = 0; }
+    FOR_GLANES { LV(mha) = LV(mhb) = LV(mna) = LV(mto) = LV(mfl) = LV(mhf) = LV(pv) = LV(stg) = LV(sdx) = LV(hop) = LV(hby) = LV(hr2) = 0; }
     uint32_t hop_at = p + 4096u; /* (out of range, as the other caches) */
     /* the two caches start out of range of p, so that their one range test fails */
     uint32_t mt_at = p + 4096u, pv_at = 0xffffffffu;
@@ -859,6 +861,7 @@ DEV void sg_parse_segment(const LzJob &job, SgLds *lds, const SgScratch &scr, ui
         uint32_t look = st.data_end - p;
         if (look < ZD_MIN_LOOKAHEAD) {
             lz_refill(job, st, p);
+            mt_at = p + 4096u; /* (the window base may have moved: the register cache holds values that depend on it) */
             look = st.data_end - p;
             if (look == 0) {
                 exit_kind = SG_EXIT_END;
@@ -968,6 +971,9 @@ DEV void sg_parse_segment(const LzJob &job, SgLds *lds, const SgScratch &scr, ui
                     LV(mhb) = rh_x >> 16;
                     LV(mna) = cn_x & 0xffffu;
                     LV(mto) = (cn_x & 0xffffu) + (cn_x >> 16);
+                    const uint32_t far_x = x - st.base > job.cfg.max_dist;
+                    LV(mfl) = far_x ? x - job.cfg.max_dist : st.base;
+                    LV(mhf) = LV(mfl) - far_x;
                 }
             }
             const uint32_t nA = GREADLANE(mna, p - mt_at), total = GREADLANE(mto, p - mt_at);
@@ -990,8 +996,7 @@ DEV void sg_parse_segment(const LzJob &job, SgLds *lds, const SgScratch &scr, ui
                 SG_COUNT(5, 1);
                 const int32_t hiA = (int32_t)GREADLANE(mha, p - mt_at), hiB = (int32_t)GREADLANE(mhb, p - mt_at);
                 const uint32_t tileA = p & ~ZD_TILE_MASK;
-                const uint32_t far = p - st.base > job.cfg.max_dist;
-                uint32_t floor_pos = far ? p - job.cfg.max_dist : st.base;
+                uint32_t floor_pos = GREADLANE(mfl, p - mt_at);
                 const uint32_t cap = look < 258u ? look : 258u;
                 const uint32_t nice = job.cfg.nice < look ? job.cfg.nice : look;
                 uint32_t best = prev_len, where = cur_at, sb = 0;
@@ -1022,7 +1027,7 @@ DEV void sg_parse_segment(const LzJob &job, SgLds *lds, const SgScratch &scr, ui
                      * A head that fails it has nothing but older entries behind it, which fail theirs: the search
                      * finds nothing, which is what not calling longest_match comes to (match_length <= prev_length
                      * either way). */
-                    const uint32_t hfloor = floor_pos - far;
+                    const uint32_t hfloor = GREADLANE(mhf, p - mt_at);
                     SG_EVAL_ONE(e0, 0u);
                     if (!bail && best < nice && total > GRP) {
                         SG_EVAL_ONE(e1, 1u);
