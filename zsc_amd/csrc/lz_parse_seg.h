@@ -842,13 +842,14 @@ DEV void sg_parse_segment(const LzJob &job, SgLds *lds, const SgScratch &scr, ui
     LANEVAR(uint32_t, mto); /* ... and in both tiles: four v_readlane and no unpacking per search */
     LANEVAR(uint32_t, mfl); /* ... the oldest position a link of its chain may have (:1519), minus one */
     LANEVAR(uint32_t, mhf); /* ... and the same for the chain head, which may lie at exactly MAX_DIST (:2032) */
+    LANEVAR(uint32_t, mby); /* ... and its four bytes of the window */
     LANEVAR(uint32_t, pv);
     LANEVAR(uint32_t, stg);
     LANEVAR(uint32_t, sdx);
     LANEVAR(uint32_t, hop); /* hops of the positions from hop_at on, and the input bytes there */
     LANEVAR(uint32_t, hby);
     LANEVAR(uint32_t, hr2); /* ... and their table entries themselves */
-    FOR_GLANES { LV(mha) = LV(mhb) = LV(mna) = LV(mto) = LV(mfl) = LV(mhf) = LV(pv) = LV(stg) = LV(sdx) = LV(hop) = LV(hby) = LV(hr2) = 0; }
+    FOR_GLANES { LV(mha) = LV(mhb) = LV(mna) = LV(mto) = LV(mfl) = LV(mhf) = LV(mby) = LV(pv) = LV(stg) = LV(sdx) = LV(hop) = LV(hby) = LV(hr2) = 0; }
     uint32_t hop_at = p + 4096u; /* (out of range, as the other caches) */
     /* the two caches start out of range of p, so that their one range test fails */
     uint32_t mt_at = p + 4096u, pv_at = 0xffffffffu;
@@ -933,9 +934,32 @@ DEV void sg_parse_segment(const LzJob &job, SgLds *lds, const SgScratch &scr, ui
                 continue;
             }
         }
-        const uint32_t rp = lz_ridx<L>(st, p);
-        uint32_t s0123;
-        SG_PEEKP(0u, s0123);
+        /* what a loop top and a search need to know of p is kept for 64 consecutive positions, a lane each */
+        if (p - mt_at >= GRP - SG_PICK_AHEAD) { /* (and the positions a search may choose its chain from) */
+            mt_at = p;
+            FOR_GLANES
+            {
+                const uint32_t x = p + (uint32_t)GLANE;
+                const int ok = x + 2 < job.n;
+                uint32_t rh_x = 0, cn_x = 0;
+                if (job.dir) {
+                    if (ok)
+                        sg_link<L>(job, lds, st, x, (uint32_t)job.rank[x], rh_x, cn_x);
+                } else {
+                    rh_x = ok ? ((uint32_t)job.rank[x] | ((uint32_t)job.hib[x] << 16)) : 0u;
+                    cn_x = ok ? job.cnt[x] : 0u;
+                }
+                LV(mha) = (rh_x & 0xffffu) - 1u;
+                LV(mhb) = rh_x >> 16;
+                LV(mna) = cn_x & 0xffffu;
+                LV(mto) = (cn_x & 0xffffu) + (cn_x >> 16);
+                const uint32_t far_x = x - st.base > job.cfg.max_dist;
+                LV(mfl) = far_x ? x - job.cfg.max_dist : st.base;
+                LV(mhf) = LV(mfl) - far_x;
+                LV(mby) = lds_u32(lds->ring, lz_ridx<L>(st, x)); /* (what lies behind the ring's data is never used) */
+            }
+        }
+        const uint32_t s0123 = GREADLANE(mby, p - mt_at);
         const uint32_t prev_len = cur_len, prev_at = cur_at;
         cur_len = 2;
         /* no hop, but the table may still know this one search: the entry itself when no match is
@@ -953,29 +977,7 @@ DEV void sg_parse_segment(const LzJob &job, SgLds *lds, const SgScratch &scr, ui
             }
         }
         if (look >= 3 && prev_len < job.cfg.lazy && !known) {
-            if (p - mt_at >= GRP - SG_PICK_AHEAD) { /* (and the positions a search may choose its chain from) */
-                mt_at = p;
-                FOR_GLANES
-                {
-                    const uint32_t x = p + (uint32_t)GLANE;
-                    const int ok = x + 2 < job.n;
-                    uint32_t rh_x = 0, cn_x = 0;
-                    if (job.dir) {
-                        if (ok)
-                            sg_link<L>(job, lds, st, x, (uint32_t)job.rank[x], rh_x, cn_x);
-                    } else {
-                        rh_x = ok ? ((uint32_t)job.rank[x] | ((uint32_t)job.hib[x] << 16)) : 0u;
-                        cn_x = ok ? job.cnt[x] : 0u;
-                    }
-                    LV(mha) = (rh_x & 0xffffu) - 1u;
-                    LV(mhb) = rh_x >> 16;
-                    LV(mna) = cn_x & 0xffffu;
-                    LV(mto) = (cn_x & 0xffffu) + (cn_x >> 16);
-                    const uint32_t far_x = x - st.base > job.cfg.max_dist;
-                    LV(mfl) = far_x ? x - job.cfg.max_dist : st.base;
-                    LV(mhf) = LV(mfl) - far_x;
-                }
-            }
+            const uint32_t rp = lz_ridx<L>(st, p);
             const uint32_t nA = GREADLANE(mna, p - mt_at), total = GREADLANE(mto, p - mt_at);
             /* A match pending: anything longer shares prev_len + 1 bytes with p, so every trigram in
              * them has been seen before -- if one of them (of those whose chain lengths are in the
