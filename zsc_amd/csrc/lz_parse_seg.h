@@ -842,14 +842,16 @@ DEV void sg_parse_segment(const LzJob &job, SgLds *lds, const SgScratch &scr, ui
     LANEVAR(uint32_t, mto); /* ... and in both tiles: four v_readlane and no unpacking per search */
     LANEVAR(uint32_t, mfl); /* ... the oldest position a link of its chain may have (:1519), minus one */
     LANEVAR(uint32_t, mhf); /* ... and the same for the chain head, which may lie at exactly MAX_DIST (:2032) */
-    LANEVAR(uint32_t, mby); /* ... and its four bytes of the window */
+    LANEVAR(uint32_t, mby); /* ... its four bytes of the window */
+    LANEVAR(uint32_t, mcp); /* ... and how long a match may get there and which length ends a search: lookahead and */
+    LANEVAR(uint32_t, mni); /*     nice_match, cut to what is left of the window's data (:1430-1436) */
     LANEVAR(uint32_t, pv);
     LANEVAR(uint32_t, stg);
     LANEVAR(uint32_t, sdx);
     LANEVAR(uint32_t, hop); /* hops of the positions from hop_at on, and the input bytes there */
     LANEVAR(uint32_t, hby);
     LANEVAR(uint32_t, hr2); /* ... and their table entries themselves */
-    FOR_GLANES { LV(mha) = LV(mhb) = LV(mna) = LV(mto) = LV(mfl) = LV(mhf) = LV(mby) = LV(pv) = LV(stg) = LV(sdx) = LV(hop) = LV(hby) = LV(hr2) = 0; }
+    FOR_GLANES { LV(mha) = LV(mhb) = LV(mna) = LV(mto) = LV(mfl) = LV(mhf) = LV(mby) = LV(mcp) = LV(mni) = LV(pv) = LV(stg) = LV(sdx) = LV(hop) = LV(hby) = LV(hr2) = 0; }
     uint32_t hop_at = p + 4096u; /* (out of range, as the other caches) */
     /* the two caches start out of range of p, so that their one range test fails */
     uint32_t mt_at = p + 4096u, pv_at = 0xffffffffu;
@@ -861,8 +863,10 @@ DEV void sg_parse_segment(const LzJob &job, SgLds *lds, const SgScratch &scr, ui
     for (;;) {
         uint32_t look = st.data_end - p;
         if (look < ZD_MIN_LOOKAHEAD) {
+            const uint32_t base0 = st.base, end0 = st.data_end;
             lz_refill(job, st, p);
-            mt_at = p + 4096u; /* (the window base may have moved: the register cache holds values that depend on it) */
+            if (st.base != base0 || st.data_end != end0)
+                mt_at = p + 4096u; /* (the window has moved: the register cache holds values that depend on it) */
             look = st.data_end - p;
             if (look == 0) {
                 exit_kind = SG_EXIT_END;
@@ -957,6 +961,9 @@ DEV void sg_parse_segment(const LzJob &job, SgLds *lds, const SgScratch &scr, ui
                 LV(mfl) = far_x ? x - job.cfg.max_dist : st.base;
                 LV(mhf) = LV(mfl) - far_x;
                 LV(mby) = lds_u32(lds->ring, lz_ridx<L>(st, x)); /* (what lies behind the ring's data is never used) */
+                const uint32_t look_x = st.data_end - x;
+                LV(mcp) = look_x < 258u ? look_x : 258u;
+                LV(mni) = job.cfg.nice < look_x ? job.cfg.nice : look_x;
             }
         }
         const uint32_t s0123 = GREADLANE(mby, p - mt_at);
@@ -999,8 +1006,7 @@ DEV void sg_parse_segment(const LzJob &job, SgLds *lds, const SgScratch &scr, ui
                 const int32_t hiA = (int32_t)GREADLANE(mha, p - mt_at), hiB = (int32_t)GREADLANE(mhb, p - mt_at);
                 const uint32_t tileA = p & ~ZD_TILE_MASK;
                 uint32_t floor_pos = GREADLANE(mfl, p - mt_at);
-                const uint32_t cap = look < 258u ? look : 258u;
-                const uint32_t nice = job.cfg.nice < look ? job.cfg.nice : look;
+                const uint32_t cap = GREADLANE(mcp, p - mt_at), nice = GREADLANE(mni, p - mt_at);
                 uint32_t best = prev_len, where = cur_at, sb = 0;
                 uint32_t budget = prev_len >= job.cfg.good ? job.cfg.chain >> 2 : job.cfg.chain;
                 int fin = 0, head_seen = 0;
