@@ -983,7 +983,10 @@ DEV void sg_parse_segment(const LzJob &job, SgLds *lds, const SgScratch &scr, ui
                 }
             }
         }
-        if (look >= 3 && prev_len < job.cfg.lazy && !known) {
+        /* (look >= 3 need not be asked: within MIN_LOOKAHEAD of the end of the window's data fill_window has run,
+         * so fewer than three bytes are only left at the end of the input, where positions own no string and
+         * their chains are empty: total == 0 below) */
+        if (prev_len < job.cfg.lazy && !known) {
             const uint32_t rp = lz_ridx<L>(st, p);
             const uint32_t nA = GREADLANE(mna, p - mt_at), total = GREADLANE(mto, p - mt_at);
             /* A match pending: anything longer shares prev_len + 1 bytes with p, so every trigram in
@@ -1020,8 +1023,10 @@ DEV void sg_parse_segment(const LzJob &job, SgLds *lds, const SgScratch &scr, ui
                 LANEVAR(uint32_t, f3);
                 SG_LOAD(e0, 0u);
                 int bail = 0, searched = 0;
-                /* (one comparison: the chain is shorter than the budget and than four loads, and there is room for a longer match) */
-                const uint32_t one_lim = best < look ? (budget < 4u * GRP + 1u ? budget : 4u * GRP + 1u) : 0u;
+                /* (one comparison: the chain is shorter than the budget and than four loads.  With no room for a
+                 * longer match -- best >= look, at the very end of the data -- no candidate gets past cap <= best
+                 * and the result is the same as that of not searching: min(best, look)) */
+                const uint32_t one_lim = budget < 4u * GRP + 1u ? budget : 4u * GRP + 1u;
                 if (SG_ONE && SG_ONE_ON && job.cfg.hbits == 15u && total < one_lim) {
                     if (total > GRP) {
                         SG_LOAD(e1, 1u);
