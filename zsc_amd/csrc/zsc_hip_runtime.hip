@@ -351,7 +351,7 @@ __global__ __launch_bounds__(SG_W * 64, SG_MIN_WAVES) void k_parse_seg(const uin
         job.cfg.chain = 128;
         job.cfg.slow = 1;
     }
-    job.strategy = buf.strategy;
+    job.strategy = LEVEL == 6 ? 0u : buf.strategy; /* (LEVEL 6 is only launched for plans without Z_FILTERED, the one strategy the lazy parse looks at) */
     job.more = buf.more;
     job.sched = sched + buf.sched_off;
     job.nsched = buf.sched_n;
@@ -1294,7 +1294,8 @@ extern "C" ZlibReturn zsc_hip_deflate_plan_run(zsc_hip_deflate_plan *pl, const v
             if (sb.cseg > 0) {
                 auto kern = (pl->wbits == 15 && pl->mem_level == 8)
                                 ? (pl->use_table ? k_parse_seg<false, true, 0>
-                                                 : pl->level == 6 ? k_parse_seg<false, false, 6> : k_parse_seg<false, false, 0>)
+                                                 : pl->level == 6 && pl->strategy != (uint32_t)Z_FILTERED ? k_parse_seg<false, false, 6>
+                                                                                                          : k_parse_seg<false, false, 0>)
                                 : k_parse_seg<true, false, 0>;
                 hipLaunchKernelGGL(kern, dim3(sb.cseg), dim3(SG_W * 64), 0, st, in, bufs,
                                    (const uint32_t *)sb.d_order.p, (const uint32_t *)sorted,
